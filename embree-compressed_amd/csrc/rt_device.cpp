@@ -1,0 +1,191 @@
+// Device: config parsing, error funnel, HIP device / stream / staging management.
+#include <cstdlib>
+#include <pthread.h>
+
+#include "rt_objects.h"
+
+namespace rtamd {
+
+RTCError& thread_error()
+{
+  static thread_local RTCError e = RTC_ERROR_NONE;
+  return e;
+}
+
+static uint64_t this_thread_key() { return (uint64_t)pthread_self(); }
+
+// Tokenizer for "key=value,key=value" strings; separators are ',' and whitespace, like the reference's
+// TokenStream-driven State::parse (kernels/common/state.cpp:241-430).  Unknown keys are skipped.
+void Device::parse(const std::string& cfg)
+{
+  size_t i = 0;
+  auto isSep = [](char c) { return c == ',' || c == ' ' || c == '\t' || c == '\n' || c == ';'; };
+  while (i < cfg.size()) {
+    while (i < cfg.size() && isSep(cfg[i])) i++;
+    size_t k0 = i;
+    while (i < cfg.size() && !isSep(cfg[i]) && cfg[i] != '=') i++;
+    std::string key = cfg.substr(k0, i - k0);
+    std::string val;
+    if (i < cfg.size() && cfg[i] == '=') {
+      i++;
+      size_t v0 = i;
+      while (i < cfg.size() && !isSep(cfg[i])) i++;
+      val = cfg.substr(v0, i - v0);
+    }
+    if (key.empty()) continue;
+    if (key == "tri_accel" || key == "accel") tri_accel = val;
+    else if (key == "subdiv_accel") subdiv_accel = val;
+    else if (key == "verbose") verbose = atoi(val.c_str());
+    else if (key == "gpu" || key == "device") gpu = (val == "none") ? -1 : atoi(val.c_str());
+    else if (key == "threads") numThreads = atoi(val.c_str());
+    else if (key == "benchmark") benchmark = atoi(val.c_str());
+    // isa, max_isa, set_affinity, affinity, start_threads, hugepages, float_exceptions, ... : x86-only, ignored
+  }
+}
+
+Device::Device(const char* cfg)
+{
+  if (const char* env = getenv("RTAMD_GPU")) gpu = atoi(env);
+  if (cfg) parse(cfg);
+  if (gpu == -1) {
+    // "gpu=none": host-only object model (build + inspect accels); every trace call raises
+    // RTC_ERROR_INVALID_OPERATION.  There is deliberately no CPU traversal in this library.
+    return;
+  }
+  int n = 0;
+  HIP_CHECK(hipGetDeviceCount(&n));
+  if (n <= 0) RT_THROW(RTC_ERROR_UNKNOWN, "no HIP device available: the traversal path has no CPU fallback");
+  if (gpu < 0 || gpu >= n) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpu ordinal out of range");
+  HIP_CHECK(hipSetDevice(gpu));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, gpu));
+  numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  ownsStream = true;
+  HIP_CHECK(hipMalloc(&countersDev, sizeof(TraceCounters)));
+  if (verbose >= 1)
+    fprintf(stderr, "embree3-amd: device %d (%s, %d CUs), tri_accel=%s subdiv_accel=%s\n", gpu, prop.name, numCUs,
+            tri_accel.c_str(), subdiv_accel.c_str());
+}
+
+Device::~Device()
+{
+  if (gpu < 0) return;
+  hipSetDevice(gpu);
+  if (stream && ownsStream) {
+    hipStreamSynchronize(stream);
+    hipStreamDestroy(stream);
+  }
+  if (stageHost) hipHostFree(stageHost);
+  if (stageDev) hipFree(stageDev);
+  if (spillDev) hipFree(spillDev);
+  if (countersDev) hipFree(countersDev);
+}
+
+void Device::useDevice() const
+{
+  if (gpu < 0) RT_THROW(RTC_ERROR_INVALID_OPERATION, "device was created with gpu=none: no HIP device, no traversal");
+  HIP_CHECK(hipSetDevice(gpu));
+}
+
+void Device::setError(RTCError code, const char* msg)
+{
+  if (verbose >= 1) {
+    static const char* names[] = {"No error", "Unknown error", "Invalid argument", "Invalid operation",
+                                  "Out of memory", "Unsupported CPU", "Cancelled"};
+    fprintf(stderr, "Embree: %s", (unsigned)code < 7 ? names[code] : "Invalid error code");
+    if (msg) fprintf(stderr, ", (%s)", msg);
+    fprintf(stderr, "\n");
+  }
+  if (errorFn) errorFn(errorFnUser, code, msg);
+  std::lock_guard<std::mutex> g(errMutex);
+  RTCError& slot = threadErrors[this_thread_key()];
+  if (slot == RTC_ERROR_NONE) slot = code; // first error wins until it is read
+}
+
+RTCError Device::takeError()
+{
+  std::lock_guard<std::mutex> g(errMutex);
+  auto it = threadErrors.find(this_thread_key());
+  if (it == threadErrors.end()) return RTC_ERROR_NONE;
+  RTCError e = it->second;
+  it->second = RTC_ERROR_NONE;
+  return e;
+}
+
+void Device::memoryMonitor(ssize_t bytes, bool post)
+{
+  if (memFn && bytes != 0) {
+    if (!memFn(memFnUser, bytes, post)) {
+      if (bytes > 0) RT_THROW(RTC_ERROR_OUT_OF_MEMORY, "memory monitor forced termination"); // device.cpp:288-298
+    }
+  }
+}
+
+void Device::ensureStaging(size_t bytes)
+{
+  if (bytes <= stageBytes) return;
+  size_t want = stageBytes ? stageBytes : (size_t)1 << 20;
+  while (want < bytes) want *= 2;
+  if (stageHost) hipHostFree(stageHost);
+  if (stageDev) hipFree(stageDev);
+  stageHost = stageDev = nullptr;
+  stageBytes = 0;
+  HIP_CHECK(hipHostMalloc(&stageHost, want, hipHostMallocDefault));
+  HIP_CHECK(hipMalloc(&stageDev, want));
+  stageBytes = want;
+}
+
+void Device::ensureSpill(size_t bytes)
+{
+  if (bytes <= spillBytes) return;
+  if (spillDev) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    hipFree(spillDev);
+    spillDev = nullptr;
+    spillBytes = 0;
+  }
+  HIP_CHECK(hipMalloc(&spillDev, bytes));
+  spillBytes = bytes;
+}
+
+// ---- Buffer ------------------------------------------------------------------------------------------
+Buffer::Buffer(Device* d, size_t n, void* sharedPtr) : device(d), bytes(n)
+{
+  device->retain();
+  if (sharedPtr) {
+    ptr = (char*)sharedPtr;
+    shared = true;
+  } else {
+    device->memoryMonitor((ssize_t)n, false);
+    // 16 bytes of slack so that float3 vertices can be read with 16-byte loads (verify.cpp:2143-2148 convention)
+    ptr = (char*)aligned_alloc(16, ((n + 15) / 16) * 16 + 16);
+    if (!ptr) RT_THROW(RTC_ERROR_OUT_OF_MEMORY, "buffer allocation failed");
+    memset(ptr, 0, ((n + 15) / 16) * 16 + 16);
+  }
+}
+
+Buffer::~Buffer()
+{
+  if (!shared && ptr) {
+    free(ptr);
+    try { device->memoryMonitor(-(ssize_t)bytes, true); } catch (...) {}
+  }
+  device->release();
+}
+
+void BufferView::set(Buffer* b, RTCFormat f, size_t off, size_t str, size_t n)
+{
+  if (b) b->retain();
+  if (buf) buf->release();
+  buf = b;
+  format = f;
+  offset = off;
+  stride = str;
+  count = n;
+  modified = true;
+}
+
+void BufferView::clear() { set(nullptr, RTC_FORMAT_UNDEFINED, 0, 0, 0); }
+
+} // namespace rtamd

@@ -1,0 +1,189 @@
+// Host object model behind the opaque embree3 handles: Device, Buffer, Geometry, Scene.
+// Mirrors the roles of kernels/common/{device,state,buffer,geometry,scene_triangle_mesh,scene_subdiv_mesh,scene}.*
+// of the reference, reduced to what the traversal hot path and its builders need.
+#pragma once
+#include <map>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
+#include "accel.h"
+#include "rt_common.h"
+
+namespace rtamd {
+
+struct Scene;
+
+// ---------------------------------------------------------------------------------------------------
+// Device: config string, error state, HIP device + stream, staging buffers.
+// ---------------------------------------------------------------------------------------------------
+struct Device : RefCounted
+{
+  // config (reference: State::parse, kernels/common/state.cpp:241-430)
+  std::string tri_accel = "default";
+  std::string subdiv_accel = "default";
+  int verbose = 0;
+  int gpu = 0;            // HIP device ordinal ("gpu=" key; falls back to env RTAMD_GPU, LOCAL_RANK is NOT read here)
+  int numThreads = 0;     // accepted, used only for host-side builders
+  int benchmark = 0;
+
+  // error state (reference: Device::process_error device.cpp:258-286, getDeviceErrorCode :250-256)
+  std::mutex errMutex;
+  std::unordered_map<uint64_t, RTCError> threadErrors; // per calling thread, first error wins
+  RTCErrorFunction errorFn = nullptr;
+  void* errorFnUser = nullptr;
+  RTCMemoryMonitorFunction memFn = nullptr;
+  void* memFnUser = nullptr;
+
+  // HIP state
+  hipStream_t stream = nullptr;
+  bool ownsStream = false;
+  std::mutex launchMutex; // serialises host-pointer batches that share the staging buffers
+
+  // staging (host-pointer path): pinned host mirror + device batch, grown on demand
+  void* stageHost = nullptr;
+  void* stageDev = nullptr;
+  size_t stageBytes = 0;
+
+  // LDS-stack overflow area and counters scratch, sized at first launch
+  void* spillDev = nullptr;
+  size_t spillBytes = 0;
+  void* countersDev = nullptr;
+  int numCUs = 256;
+
+  explicit Device(const char* cfg);
+  ~Device() override;
+
+  void parse(const std::string& cfg);
+  void setError(RTCError code, const char* msg);
+  RTCError takeError();
+  void useDevice() const; // hipSetDevice(gpu) for the calling thread
+  void ensureStaging(size_t bytes);
+  void ensureSpill(size_t bytes);
+  void memoryMonitor(ssize_t bytes, bool post);
+};
+
+// thread-local error slot used when no device exists yet (rtcNewDevice failure; device.cpp:262-263)
+RTCError& thread_error();
+
+// ---------------------------------------------------------------------------------------------------
+// Buffer: owned or shared (borrowed) byte range.
+// ---------------------------------------------------------------------------------------------------
+struct Buffer : RefCounted
+{
+  Device* device;
+  char* ptr = nullptr;
+  size_t bytes = 0;
+  bool shared = false;
+  Buffer(Device* d, size_t n, void* sharedPtr);
+  ~Buffer() override;
+};
+
+// A typed view into a Buffer as bound to a geometry slot (reference: RawBufferView, kernels/common/buffer.h).
+struct BufferView
+{
+  Buffer* buf = nullptr;
+  RTCFormat format = RTC_FORMAT_UNDEFINED;
+  size_t offset = 0, stride = 0, count = 0;
+  bool modified = true;
+  const char* at(size_t i) const { return buf->ptr + offset + i * stride; }
+  bool valid() const { return buf != nullptr; }
+  void set(Buffer* b, RTCFormat f, size_t off, size_t str, size_t n);
+  void clear();
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Geometry
+// ---------------------------------------------------------------------------------------------------
+struct Geometry : RefCounted
+{
+  Device* device;
+  RTCGeometryType type;
+  bool enabled = true;
+  bool committed = false;
+  unsigned mask = 0xFFFFFFFFu;
+  unsigned timeSteps = 1;
+  RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
+  void* userPtr = nullptr;
+  RTCFilterFunctionN intersectFilter = nullptr;
+  RTCFilterFunctionN occludedFilter = nullptr;
+  RTCDisplacementFunctionN displacement = nullptr;
+  float tessellationRate = 2.0f;
+  unsigned vertexAttribCount = 0;
+  unsigned topologyCount = 1;
+  std::vector<RTCSubdivisionMode> subdivMode{RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY};
+
+  // buffer slots, keyed by (type, slot)
+  std::map<std::pair<int, unsigned>, BufferView> views;
+
+  Geometry(Device* d, RTCGeometryType t);
+  ~Geometry() override;
+
+  BufferView* view(RTCBufferType t, unsigned slot);
+  const BufferView* view(RTCBufferType t, unsigned slot) const;
+  void bind(RTCBufferType t, unsigned slot, RTCFormat f, Buffer* b, size_t off, size_t stride, size_t count);
+
+  // triangle mesh accessors (reference: TriangleMesh, kernels/common/scene_triangle_mesh.h)
+  size_t numTriangles() const;
+  size_t numVertices() const;
+  void triangle(size_t i, unsigned idx[3]) const;
+  V3 vertex(size_t i) const;
+  bool validTriangle(size_t i) const;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Scene
+// ---------------------------------------------------------------------------------------------------
+// One device accel: host mirror (for tests / stats) + HBM arrays.
+struct Accel
+{
+  std::vector<QNode8> nodes;
+  std::vector<TriRecord> prims;
+  std::vector<uint8_t> blobs;
+  std::vector<uint32_t> blobOffsets;
+  uint32_t root = REF_EMPTY;
+  uint32_t kind = ACCEL_NONE;
+  uint32_t robust = 0;
+  uint32_t maxDepth = 0;
+  size_t leafCount = 0;
+  // device copies
+  void* dNodes = nullptr;
+  void* dPrims = nullptr;
+  void* dBlobs = nullptr;
+  void* dBlobOffsets = nullptr;
+  AccelDesc desc() const;
+  size_t deviceBytes() const;
+  void upload(Device* dev);
+  void freeDevice();
+  void clear();
+};
+
+struct Scene : RefCounted
+{
+  Device* device;
+  std::vector<Geometry*> geometries; // index = geomID, nullptr = free slot
+  RTCSceneFlags flags = RTC_SCENE_FLAG_NONE;
+  RTCBuildQuality quality = RTC_BUILD_QUALITY_MEDIUM;
+  unsigned subdivisionLevel = 6; // fork defaults, kernels/common/scene.cpp:41-42
+  unsigned compressionLevel = 3;
+  RTCProgressMonitorFunction progressFn = nullptr;
+  void* progressUser = nullptr;
+  bool modified = true; // "scene got not committed" until the first commit (scene.cpp:25,54)
+  std::mutex buildMutex;
+  Box3 bounds;
+
+  Accel triAccel;    // triangles
+  Accel subdivAccel; // subdivision patches (cBVH / GridSOA leaves)
+
+  explicit Scene(Device* d);
+  ~Scene() override;
+
+  unsigned attach(Geometry* g);
+  void attachByID(Geometry* g, unsigned id);
+  void detach(unsigned id);
+  Geometry* get(unsigned id) const;
+  void commit();
+  bool isRobust() const { return (flags & RTC_SCENE_FLAG_ROBUST) != 0; }
+};
+
+} // namespace rtamd

@@ -1,0 +1,106 @@
+// Batch front-end of the hot path: host/device pointer handling, staging, kernel launches.
+// Replaces RayStreamFilter::filterAOS (kernels/bvh/bvh_intersector_stream_filters.cpp:24-165) and the
+// per-ray dispatch through Accel::Intersectors (kernels/common/accel.h:264-267).
+#include "rt_trace.h"
+
+namespace rtamd {
+
+static bool is_device_pointer(const void* p)
+{
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError(); // plain (unregistered) host memory
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
+                      TraceCounters* dCounters)
+{
+  Device* dev = s->device;
+  if (A.kind == ACCEL_NONE || A.root == REF_EMPTY) return;
+  LaunchParams p;
+  p.accel = A.desc();
+  p.rays = dRays;
+  p.count = M;
+  p.stride = stride;
+  p.instID = instID;
+  p.occluded = occluded ? 1u : 0u;
+  p.gridBlocks = trace_grid_blocks(M, dev->numCUs);
+  // worst-case stack: 7 siblings per level plus the entry being expanded
+  const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
+  p.spillDepth = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
+  dev->ensureSpill((size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u);
+  p.spill = dev->spillDev;
+  p.counters = dCounters;
+  HIP_CHECK(launch_trace(p, dev->stream));
+}
+
+void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx,
+                 TraceCounters* countersOut)
+{
+  Device* dev = s->device;
+  if (s->modified) RT_THROW(RTC_ERROR_INVALID_OPERATION, "scene got not committed"); // scene.cpp:25,54
+  if (M == 0) return;
+  dev->useDevice();
+  if (ctx && ctx->filter) RT_THROW(RTC_ERROR_INVALID_OPERATION, "context filter functions are not run by the device path");
+  if (byteStride > 0xFFFFFFFFull) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "byteStride too large");
+  if (((uintptr_t)rays) & 3) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "ray not aligned to 4 bytes"); // rtcore.cpp:413
+  const uint32_t instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
+  const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
+
+  TraceCounters* dCounters = nullptr;
+  if (countersOut) {
+    dCounters = (TraceCounters*)dev->countersDev;
+    HIP_CHECK(hipMemsetAsync(dCounters, 0, sizeof(TraceCounters), dev->stream));
+  }
+
+  if (is_device_pointer(rays)) {
+    // device-resident stream: trace in place, stream-ordered, no host synchronisation
+    launch_on(s, s->triAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
+    launch_on(s, s->subdivAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
+  } else {
+    std::lock_guard<std::mutex> lock(dev->launchMutex);
+    const size_t bytes = (size_t)M * rec;
+    dev->ensureStaging(bytes);
+    char* h = (char*)dev->stageHost;
+    if (byteStride == rec) memcpy(h, rays, bytes);
+    else
+      for (uint32_t i = 0; i < M; i++) memcpy(h + (size_t)i * rec, (const char*)rays + (size_t)i * byteStride, rec);
+    HIP_CHECK(hipMemcpyAsync(dev->stageDev, h, bytes, hipMemcpyHostToDevice, dev->stream));
+    launch_on(s, s->triAccel, dev->stageDev, M, rec, occluded, instID, dCounters);
+    launch_on(s, s->subdivAccel, dev->stageDev, M, rec, occluded, instID, dCounters);
+    HIP_CHECK(hipMemcpyAsync(h, dev->stageDev, bytes, hipMemcpyDeviceToHost, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    // only tfar (byte 32) and the hit record (bytes 48..79) are outputs
+    for (uint32_t i = 0; i < M; i++) {
+      char* dst = (char*)rays + (size_t)i * byteStride;
+      const char* src = h + (size_t)i * rec;
+      memcpy(dst + 32, src + 32, 4);
+      if (!occluded) memcpy(dst + 48, src + 48, 32);
+    }
+  }
+
+  if (countersOut) {
+    HIP_CHECK(hipMemcpyAsync(countersOut, dCounters, sizeof(TraceCounters), hipMemcpyDeviceToHost, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+  }
+}
+
+void trace_pointers(Scene* s, void** ptrs, uint32_t M, bool occluded, const RTCIntersectContext* ctx)
+{
+  // rtcIntersect1Mp / rtcOccluded1Mp: gather the pointed-to records into one batch (filterAOP, filters.cpp:167-)
+  const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
+  std::vector<char> tmp((size_t)M * rec + 16);
+  char* base = (char*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
+  for (uint32_t i = 0; i < M; i++) memcpy(base + (size_t)i * rec, ptrs[i], rec);
+  trace_batch(s, base, M, rec, occluded, ctx, nullptr);
+  for (uint32_t i = 0; i < M; i++) {
+    memcpy((char*)ptrs[i] + 32, base + (size_t)i * rec + 32, 4);
+    if (!occluded) memcpy((char*)ptrs[i] + 48, base + (size_t)i * rec + 48, 32);
+  }
+}
+
+} // namespace rtamd

@@ -1,0 +1,32 @@
+// Launch interface between the host object model and the HIP traversal kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "accel.h"
+
+namespace rtamd {
+
+struct LaunchParams
+{
+  AccelDesc accel;
+  void* rays;          // device pointer to the first RTCRayHit (intersect) or RTCRay (occluded)
+  uint32_t count;      // M
+  uint32_t stride;     // byteStride
+  uint32_t instID;     // context->instID[0], copied into hit.instID (intersector_epilog.h:303)
+  uint32_t occluded;   // 0: closest hit, 1: any hit
+  void* spill;         // HBM overflow area of the per-lane LDS stacks
+  uint32_t spillDepth; // entries per lane available in `spill`
+  uint32_t gridBlocks; // persistent grid size the spill area was sized for
+  TraceCounters* counters; // non-null selects the instrumented kernel twin
+};
+
+static const int TRACE_BLOCK = 256;     // 4 wavefronts per workgroup
+static const int TRACE_LDS_STACK = 16;  // stack entries per lane kept in LDS (8 bytes each -> 32 KiB / workgroup)
+
+// Number of workgroups of the persistent grid for `count` rays on a chip with `numCUs` compute units.
+uint32_t trace_grid_blocks(uint32_t count, int numCUs);
+
+// Enqueue traversal of one batch on `stream`.  Asynchronous; errors surface through hipGetLastError.
+hipError_t launch_trace(const LaunchParams& p, hipStream_t stream);
+
+} // namespace rtamd

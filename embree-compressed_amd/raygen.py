@@ -1,0 +1,58 @@
+"""Synthetic ray batches of the BASELINE workload, generated without libc and without the oracle.
+
+`make_random_rays` reproduces the reference viewer's random-ray benchmark generator (makeRandomRay,
+tutorials/viewer/viewer_device.cpp:367-392): two points uniform in the scene's bounding box from a
+drand48-compatible 48-bit LCG, org = p1, dir = normalize(p2 - p1), tnear = 0, tfar = inf.  The LCG is
+evaluated with log-doubling jump-ahead in numpy so that multi-million-ray batches take milliseconds.
+"""
+import numpy as np
+
+_A = np.uint64(0x5DEECE66D)
+_C = np.uint64(0xB)
+_MASK = np.uint64((1 << 48) - 1)
+
+RAYHIT_BYTES = 80
+
+
+def lcg48_sequence(n, seed):
+    """x_1..x_n of drand48 after srand48(seed) as uint64 (48-bit states)."""
+    x0 = np.uint64(((seed & 0xFFFFFFFF) << 16) | 0x330E)
+    out = np.empty(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        out[0] = (_A * x0 + _C) & _MASK
+        # (a_k, c_k): x_{i+k} = a_k x_i + c_k ; doubling: a_2k = a_k^2, c_2k = a_k c_k + c_k  (mod 2^48 via uint64 wrap)
+        a, c, k = _A, _C, 1
+        while k < n:
+            m = min(k, n - k)
+            out[k:k + m] = (a * out[:m] + c) & _MASK
+            c = (a * c + c) & _MASK
+            a = (a * a) & _MASK
+            k *= 2
+    return out
+
+
+def make_random_rays(m, lo, hi, seed=0):
+    """Returns a uint8 array [m, 80] of RTCRayHit records (BASELINE.md section 3, fp32 evaluation)."""
+    lo = np.asarray(lo, dtype=np.float32)
+    hi = np.asarray(hi, dtype=np.float32)
+    u = (lcg48_sequence(6 * m, seed).astype(np.float64) * (1.0 / 281474976710656.0)).astype(np.float32).reshape(m, 2, 3)
+    diam = (hi - lo).astype(np.float32)
+    p = (u * diam[None, None, :]).astype(np.float32) + lo[None, None, :]
+    d = (p[:, 1, :] - p[:, 0, :]).astype(np.float32)
+    sq = (d * d).astype(np.float32)
+    length = np.sqrt(((sq[:, 0] + sq[:, 1]).astype(np.float32) + sq[:, 2]).astype(np.float32)).astype(np.float32)
+    d = (d / length[:, None]).astype(np.float32)
+    rec = np.zeros((m, 20), dtype=np.float32)
+    rec[:, 0:3] = p[:, 0, :]
+    rec[:, 4:7] = d
+    rec[:, 8] = np.inf
+    w = rec.view(np.uint32)
+    w[:, 9] = 0xFFFFFFFF
+    w[:, 10] = np.arange(m, dtype=np.uint32)
+    w[:, 17:20] = 0xFFFFFFFF
+    return rec.view(np.uint8).reshape(m, RAYHIT_BYTES)
+
+
+def shard_range(total, rank, world):
+    """Contiguous ray-index range of `rank`: [rank*total/world, (rank+1)*total/world)."""
+    return (rank * total) // world, ((rank + 1) * total) // world

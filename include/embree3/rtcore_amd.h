@@ -1,0 +1,76 @@
+/*
+ * MI355X extensions to the embree3 contract.  These are additions, not replacements: the reference has
+ * no counterpart because it has no device, no stream and no batch boundary.  They exist so that a caller
+ * who already owns device-resident ray buffers (bench.py, a wavefront renderer) can run the hot path
+ * without host staging and can time / inspect it.
+ *
+ * Everything here is plain C ABI: opaque handles from rtcore.h, void* for HIP handles, sized structs.
+ */
+#ifndef EMBREE3_AMD_RTCORE_AMD_H
+#define EMBREE3_AMD_RTCORE_AMD_H
+
+#include "rtcore.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+/* HIP stream (hipStream_t as void*) on which the device enqueues uploads and traversal kernels.
+ * rtcIntersect1M/rtcOccluded1M on DEVICE pointers are stream-ordered on it and return without a host
+ * sync; on HOST pointers they synchronise before returning (embree semantics). */
+RTC_API void* rtcamdGetDeviceStream(RTCDevice device);
+/* Use a caller-owned stream (e.g. the framework's current stream) instead of the library's own. */
+RTC_API void rtcamdSetDeviceStream(RTCDevice device, void* hipStream);
+/* Block until everything enqueued on the device's stream has completed. */
+RTC_API void rtcamdSynchronizeDevice(RTCDevice device);
+/* HIP device ordinal the RTCDevice was created on (config key "gpu="). */
+RTC_API int rtcamdGetDeviceOrdinal(RTCDevice device);
+
+/* Layout facts of a committed scene's device acceleration structure; sizes in bytes.
+ * Replaces what the reference prints with verbose=2 (kernels/bvh/bvh_statistics.cpp). */
+struct RTCAMDSceneStats
+{
+  size_t byteSize;          /* sizeof(struct RTCAMDSceneStats), set by the caller */
+  unsigned int accelKind;   /* 0 none, 1 bvh8.triangle4v (Pluecker), 2 bvh8.triangle4 (Moeller),
+                               3 cbvh.box, 4 cbvh.leaf, 5 cbvh.grid, 6 gridsoa (eager) */
+  unsigned int branching;   /* 8 */
+  size_t nodeCount;         /* quantized BVH8 nodes */
+  size_t nodeBytes;         /* bytes per node record (96) */
+  size_t primCount;         /* triangles, or cBVH / GridSOA leaves */
+  size_t primBytes;         /* bytes per triangle record (48) or mean bytes per subdiv leaf blob */
+  size_t leafCount;         /* BVH8 leaves */
+  size_t totalBytes;        /* resident HBM bytes of the accel */
+  unsigned int maxDepth;
+  unsigned int reserved;
+};
+RTC_API void rtcamdGetSceneStats(RTCScene scene, struct RTCAMDSceneStats* stats);
+
+/* Per-batch traversal work counters, produced by an instrumented twin of the intersect kernel (same
+ * code path, atomics added).  The batch is traced exactly like rtcIntersect1M does.  Used to price the
+ * algorithmic bytes per ray, B = 84 + nodes*nodeBytes + prims*primBytes; the
+ * reference's counterpart is the EMBREE_STAT_COUNTERS build (kernels/common/stat.h:21-33). */
+struct RTCAMDTraceCounters
+{
+  unsigned long long rays;        /* valid rays traced */
+  unsigned long long nodeVisits;  /* BVH8 node records fetched */
+  unsigned long long leafVisits;  /* BVH8 leaves entered */
+  unsigned long long primTests;   /* triangle records fetched / cBVH or grid leaves entered */
+  unsigned long long innerVisits; /* cBVH-internal 4-byte nodes decoded / GridSOA cells tested */
+  unsigned long long hits;        /* rays that report a hit */
+  unsigned long long stackSpills; /* pushes that overflowed the LDS stack into the HBM spill area */
+  unsigned long long reserved;
+};
+RTC_API void rtcamdIntersect1MCounted(RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit* rayhit,
+                                      unsigned int M, size_t byteStride, struct RTCAMDTraceCounters* counters);
+
+/* Read-only views of the host copy of the committed accel (valid until the next commit / release).
+ * Test infrastructure: lets an external checker walk the exact structure the kernels traverse.
+ * kind: 0 = BVH8 nodes, 1 = primitive records, 2 = subdiv leaf blobs, 3 = blob offset table. */
+RTC_API const void* rtcamdGetAccelData(RTCScene scene, unsigned int kind, size_t* byteSize);
+/* Root reference of the BVH8 (encoding documented in DESIGN.md / csrc/accel.h). */
+RTC_API unsigned int rtcamdGetAccelRoot(RTCScene scene);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

@@ -1,0 +1,3 @@
+/* Forwarder: the whole embree3 contract lives in rtcore.h (reference twin: include/embree3/rtcore_version.h). */
+#pragma once
+#include "rtcore.h"

@@ -1,0 +1,64 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's single-ray traversal hot path, used solely as the checker in
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing in embree-compressed_amd/
+ * includes, links or executes this code.
+ *
+ * Parity pinning (see DESIGN.md "Oracle"):
+ *   - triangle path: pinned by the reference's known-answer test TriangleHitTest (tutorials/verify/verify.cpp:
+ *     2118-2205, restated in tests/test_oracle_kat.py), by the reference outputs recorded in SURVEY.md section 8d
+ *     (227 188 hits / sum primID 10 389 122 on the 1 M-ray bomberman set), and by oracle/_ref (the reference's own
+ *     common/math + common/simd headers compiled in place) for the arithmetic primitives.
+ *   - cBVH / GridSOA paths: "parity unpinned" beyond the hit-count anchors of SURVEY.md section 6.
+ */
+#ifndef EMBREE_ORACLE_H
+#define EMBREE_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_scene orc_scene;
+
+/* mode 0: BVH8 + Triangle4v, robust traversal, Pluecker test   (bvh_intersector1_bvh8.cpp:29)
+ * mode 1: BVH8 + Triangle4,  fast traversal,   Moeller test     (bvh_intersector1_bvh8.cpp:27)
+ * verts: nverts x 3 floats; tris: ntris x 3 vertex indices; geomIDs / primIDs: per triangle (NULL -> 0 / index). */
+orc_scene* orc_scene_new_triangles(const float* verts, size_t nverts, const uint32_t* tris, const uint32_t* geomIDs,
+                                   const uint32_t* primIDs, size_t ntris, int mode);
+void orc_scene_free(orc_scene* s);
+
+/* rayhit: embree3 RTCRayHit layout (80 bytes); ray: RTCRay layout (48 bytes). */
+void orc_intersect1(const orc_scene* s, void* rayhit, uint32_t instID);
+void orc_occluded1(const orc_scene* s, void* ray);
+
+/* Stream versions with the semantics of rtcIntersect1M / rtcOccluded1M (rays with tnear > tfar are skipped).
+ * nthreads > 1 splits the range into blocks of 1024 rays over that many pthreads (verify.cpp:3850-3857 style). */
+void orc_intersect1M(const orc_scene* s, void* rayhits, uint32_t M, size_t byteStride, uint32_t instID, int nthreads);
+void orc_occluded1M(const orc_scene* s, void* rays, uint32_t M, size_t byteStride, int nthreads);
+
+/* Work counters of the last single-threaded orc_intersect1M call (nodes, leaves, blocks), like EMBREE_STAT_COUNTERS. */
+void orc_get_counters(unsigned long long out[3]);
+
+/* Arithmetic primitives, exported so that tests can compare them with oracle/_ref. */
+float orc_rcp(float x);
+void orc_cross(const float a[3], const float b[3], float out[3]);
+float orc_dot(const float a[3], const float b[3]);
+void orc_stable_triangle_normal(const float a[3], const float b[3], const float c[3], float out[3]);
+/* one Triangle4v block vs one ray: returns lane (0..3) of the accepted hit or -1; out = t,u,v,Ngx,Ngy,Ngz */
+int orc_pluecker_block(const float v0[12], const float v1[12], const float v2[12], const float org[3], const float dir[3],
+                       float tnear, float tfar, float out[6]);
+int orc_moeller_block(const float v0[12], const float v1[12], const float v2[12], const float org[3], const float dir[3],
+                      float tnear, float tfar, float out[6]);
+
+/* drand48-compatible 48-bit LCG ray generator of BASELINE.md section 3 (viewer_device.cpp:367-392). */
+void orc_make_random_rays(void* rayhits, uint32_t M, size_t byteStride, const float lo[3], const float hi[3], uint64_t seed,
+                          int doubleEval);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
