@@ -52,7 +52,7 @@ def cpu_baseline(verts, tris, lo, hi, m, budget_s, mode):
     orc = po.TriangleScene(verts, tris, mode)
     src = po.make_random_rays(m, lo, hi, seed=12345)
     total, spent, reps = 0, 0.0, 0
-    while spent < budget_s and reps < 64:
+    while spent < budget_s and reps < 4096:
         work = src.copy()
         t0 = time.perf_counter()
         orc.intersect1M(work, nthreads=cores)

@@ -67,6 +67,14 @@ def load_library(path=LIB_PATH):
     if not os.path.exists(path):
         raise ImportError(f"{path} not found: build it with `make -C embree-compressed_amd` "
                           f"(or __graft_entry__.build()); there is no fallback implementation")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64.so.  If this
+    # library were loaded first it would bind the system copies and torch would then find "no HIP GPUs".  Importing
+    # torch first makes the dynamic loader resolve our NEEDED libamdhip64.so.7 to the copy torch already mapped, so
+    # torch tensors and this library share one runtime (device pointers, streams and events are interchangeable).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     vp, u, sz = C.c_void_p, C.c_uint, C.c_size_t
     sig = {
