@@ -61,6 +61,45 @@ struct alignas(16) TriRecord
 };
 static_assert(sizeof(TriRecord) == 48, "TriRecord must be 48 bytes");
 
+// ---- eager subdivision leaf: one 3x3-vertex cell (2x2 quads = 8 triangles), 160 bytes = 10 x dwordx4 ------
+// Replaces the inner leaves of GridSOA (kernels/geometry/grid_soa.h:267-286, :85-90): the reference stores whole
+// <=9x9 sub-grids in SoA form and a private BVH4 down to 3x3-vertex cells; here every cell is self-contained and the
+// scene BVH8 goes straight down to cells.  p[r*3+c] is the vertex in row r (v direction), column c (u direction);
+// uv[] holds the reference's packed patch coordinates (v16<<16 | u16, scale 8/65536, grid_soa.cpp:48-52).
+struct alignas(16) GridCell
+{
+  float px[9], py[9], pz[9];
+  uint32_t uv[9];
+  uint32_t geomID, primID;
+  uint32_t pad[2];
+};
+static_assert(sizeof(GridCell) == 160, "GridCell must be 160 bytes");
+
+// ---- fork: compressed per-sub-grid BVH ("cBVH") blob -------------------------------------------------------------
+// Header (CBVH_HEADER_BYTES) followed by elems 4-byte nodes, then (leaf mode) 4^C 2-byte height patches, then (grid
+// mode) (2^C+1)^2 float3 vertices; blob stride is a multiple of 16.  Mirrors CompressedBVH's members
+// (kernels/geometry/compressed.h:408-433) with offsets instead of host pointers, the 3x3 inverse of proj precomputed
+// (the reference inverts at run time, compressed.h:585,647), and the leaf's world bounds kept for the any-hit stub.
+struct alignas(16) CbvhHeader
+{
+  uint32_t geomID, primID;
+  float uv0x, uv0y, uv1x, uv1y; // uv[0], uv[1]
+  float rcp_edges;
+  float extent;
+  uint32_t elems;       // (4^C-1)/3 inner nodes
+  uint32_t grid_width;  // 2^C+1
+  uint32_t levels;      // C
+  uint32_t pad0;
+  float space[9];       // rows of the 3x3 world->local matrix: l = (dot(row0,p), dot(row1,p), dot(row2,p))
+  float proj[9];        // row-major homography
+  float iproj[9];       // row-major inverse homography
+  float box[10];        // frustum: z slab + four 2-D corner points (compressed.h:278-292)
+  float wlo[3], whi[3]; // world-space bounds handed to the outer BVH (bounds_o)
+  float pad1;
+};
+static const uint32_t CBVH_HEADER_BYTES = 224;
+static_assert(sizeof(CbvhHeader) == CBVH_HEADER_BYTES, "CbvhHeader must be 224 bytes");
+
 enum AccelKind : uint32_t
 {
   ACCEL_NONE = 0,
@@ -82,7 +121,7 @@ struct AccelDesc
   uint32_t root;               // REF_EMPTY for an empty scene
   uint32_t kind;               // AccelKind
   uint32_t robust;             // 1: robust node test (TravRay<...,true>), 0: fast test
-  uint32_t pad;
+  uint32_t blobStride;          // bytes per leaf blob (GridCell: 160; cBVH: header + nodes + leaves/grid)
 };
 
 // Work counters of the instrumented kernels (mirrors RTCAMDTraceCounters).

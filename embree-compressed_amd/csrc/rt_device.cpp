@@ -39,6 +39,7 @@ void Device::parse(const std::string& cfg)
     else if (key == "gpu" || key == "device") gpu = (val == "none") ? -1 : atoi(val.c_str());
     else if (key == "threads") numThreads = atoi(val.c_str());
     else if (key == "benchmark") benchmark = atoi(val.c_str());
+    else if (key == "keep_grids") keepGrids = atoi(val.c_str());
     // isa, max_isa, set_affinity, affinity, start_threads, hugepages, float_exceptions, ... : x86-only, ignored
   }
 }

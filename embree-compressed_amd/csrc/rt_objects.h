@@ -26,6 +26,7 @@ struct Device : RefCounted
   int gpu = 0;            // HIP device ordinal ("gpu=" key; falls back to env RTAMD_GPU, LOCAL_RANK is NOT read here)
   int numThreads = 0;     // accepted, used only for host-side builders
   int benchmark = 0;
+  int keepGrids = 0;      // "keep_grids=1": keep the tessellated vertex grids for inspection (tests)
 
   // error state (reference: Device::process_error device.cpp:258-286, getDeviceErrorCode :250-256)
   std::mutex errMutex;
@@ -145,6 +146,7 @@ struct Accel
   uint32_t kind = ACCEL_NONE;
   uint32_t robust = 0;
   uint32_t maxDepth = 0;
+  uint32_t blobStride = 0;
   size_t leafCount = 0;
   // device copies
   void* dNodes = nullptr;
@@ -171,6 +173,8 @@ struct Scene : RefCounted
   bool modified = true; // "scene got not committed" until the first commit (scene.cpp:25,54)
   std::mutex buildMutex;
   Box3 bounds;
+
+  std::vector<uint8_t> debugGrids; // keep_grids=1: per patch {geomID,primID,n} + x[],y[],z[] of the (n+1)^2 grid
 
   Accel triAccel;    // triangles
   Accel subdivAccel; // subdivision patches (cBVH / GridSOA leaves)

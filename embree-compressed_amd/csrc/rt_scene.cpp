@@ -119,7 +119,7 @@ AccelDesc Accel::desc() const
   d.root = root;
   d.kind = kind;
   d.robust = robust;
-  d.pad = 0;
+  d.blobStride = blobStride;
   return d;
 }
 

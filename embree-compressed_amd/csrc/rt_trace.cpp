@@ -5,6 +5,14 @@
 
 namespace rtamd {
 
+uint32_t trace_grid_blocks(uint32_t count, int numCUs)
+{
+  // 32 KiB of LDS stack per workgroup -> 5 resident workgroups (20 waves) per CU
+  const uint32_t resident = (uint32_t)numCUs * 5u;
+  const uint32_t need = (count + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  return need < resident ? (need ? need : 1u) : resident;
+}
+
 static bool is_device_pointer(const void* p)
 {
   hipPointerAttribute_t attr;
@@ -35,6 +43,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   dev->ensureSpill((size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u);
   p.spill = dev->spillDev;
   p.counters = dCounters;
+  p.cbvhLevels = s->compressionLevel;
   HIP_CHECK(launch_trace(p, dev->stream));
 }
 

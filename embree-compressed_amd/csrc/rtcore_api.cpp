@@ -577,8 +577,8 @@ API void rtcamdGetSceneStats(RTCScene h, struct RTCAMDSceneStats* st)
   st->nodeCount = A.nodes.size();
   st->nodeBytes = sizeof(QNode8);
   const bool tri = A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER;
-  st->primCount = tri ? A.prims.size() : A.blobOffsets.size();
-  st->primBytes = tri ? sizeof(TriRecord) : (A.blobOffsets.empty() ? 0 : A.blobs.size() / A.blobOffsets.size());
+  st->primCount = tri ? A.prims.size() : (A.blobStride ? A.blobs.size() / A.blobStride : 0);
+  st->primBytes = tri ? sizeof(TriRecord) : A.blobStride;
   st->leafCount = A.leafCount;
   st->totalBytes = S(h)->triAccel.deviceBytes() + S(h)->subdivAccel.deviceBytes();
   st->maxDepth = A.maxDepth;
@@ -610,6 +610,7 @@ API const void* rtcamdGetAccelData(RTCScene h, unsigned int kind, size_t* byteSi
   case 1: p = A.prims.data(); n = A.prims.size() * sizeof(TriRecord); break;
   case 2: p = A.blobs.data(); n = A.blobs.size(); break;
   case 3: p = A.blobOffsets.data(); n = A.blobOffsets.size() * 4; break;
+  case 4: p = S(h)->debugGrids.data(); n = S(h)->debugGrids.size(); break;
   default: RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown accel data kind");
   }
   if (byteSize) *byteSize = n;

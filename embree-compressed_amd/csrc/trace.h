@@ -17,6 +17,7 @@ struct LaunchParams
   void* spill;         // HBM overflow area of the per-lane LDS stacks
   uint32_t spillDepth; // entries per lane available in `spill`
   uint32_t gridBlocks; // persistent grid size the spill area was sized for
+  uint32_t cbvhLevels; // fork: depth C of every cBVH blob of the scene (rtcSetSceneLevels)
   TraceCounters* counters; // non-null selects the instrumented kernel twin
 };
 
@@ -26,7 +27,20 @@ static const int TRACE_LDS_STACK = 16;  // stack entries per lane kept in LDS (8
 // Number of workgroups of the persistent grid for `count` rays on a chip with `numCUs` compute units.
 uint32_t trace_grid_blocks(uint32_t count, int numCUs);
 
-// Enqueue traversal of one batch on `stream`.  Asynchronous; errors surface through hipGetLastError.
-hipError_t launch_trace(const LaunchParams& p, hipStream_t stream);
+// Enqueue traversal of one batch on `stream`.  Asynchronous; errors surface through the returned hipError_t.
+hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream);    // trace_tri.hip
+hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream); // trace_subdiv.hip
+inline hipError_t launch_trace(const LaunchParams& p, hipStream_t stream)
+{
+  switch (p.accel.kind) {
+  case ACCEL_TRI_PLUECKER:
+  case ACCEL_TRI_MOELLER: return launch_trace_tri(p, stream);
+  case ACCEL_CBVH_BOX:
+  case ACCEL_CBVH_LEAF:
+  case ACCEL_CBVH_GRID:
+  case ACCEL_GRIDSOA: return launch_trace_subdiv(p, stream);
+  default: return hipSuccess;
+  }
+}
 
 } // namespace rtamd

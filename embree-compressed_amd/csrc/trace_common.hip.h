@@ -1,0 +1,443 @@
+// Device-side skeleton shared by all traversal kernels (gfx950): ray state, per-ray node-test constants,
+// the quantized-BVH8 while-while traversal loop with the per-lane LDS stack, and the triangle edge tests.
+//
+// One ray per lane, 64 rays per wavefront, persistent grid-stride over the batch.  Each lane keeps its
+// traversal stack in LDS (entry-major layout stack[entry][lane]: bank = lane, so the lanes of a wave never
+// conflict whatever their individual stack depths) with an HBM overflow area for pathological depths.
+// Node records are 96 bytes fetched as six dwordx4.  No MFMA: branchy slab / edge-function arithmetic.
+//
+// Restated reference algorithms (semantics kept, code new):
+//   traversal loop        kernels/bvh/bvh_intersector1.cpp:40-126 (intersect), :128-209 (occluded)
+//   TravRay precompute    kernels/bvh/node_intersector1.h:33-105 (fast), :108-177 (robust)
+//   slab tests            node_intersector1.h:249-286 (fast, FMA form), :334-349 (robust)
+//   child ordering        kernels/bvh/bvh_traverser1.h:549-666 + kernels/common/stack_item.h:39-80
+//   Pluecker test         kernels/geometry/triangle_intersector_pluecker.h:79-132, finalize :41-51
+//   Moeller test          kernels/geometry/triangle_intersector_moeller.h:75-113, finalize :42-48
+//   FMA placement         common/math/vec3.h:193-212 (dot, cross, stable_triangle_normal)
+// Compiled with -ffp-contract=off: every fused multiply-add below is explicit, exactly where the
+// reference's AVX2 build has one.
+//
+// A kernel is this skeleton instantiated with a Leaf policy:
+//   struct Leaf { static __device__ bool intersect<OCCLUDED,COUNT>(const LaunchParams&, uint32_t ref, RayState&, WorkCounters&); }
+// returning true when an any-hit query is finished (ray occluded).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "accel.h"
+#include "trace.h"
+
+namespace rtamd {
+namespace dev {
+
+struct WorkCounters
+{
+  unsigned long long nodes = 0, leaves = 0, prims = 0, inner = 0, hits = 0, rays = 0, spills = 0;
+};
+
+#define RT_INF __builtin_huge_valf()
+
+__device__ __forceinline__ float msub(float a, float b, float c) { return __builtin_fmaf(a, b, -c); } // a*b-c fused
+__device__ __forceinline__ float madd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+  return madd(ax, bx, madd(ay, by, az * bz)); // vec3.h:193
+}
+__device__ __forceinline__ float xorf(float a, uint32_t signbit) { return __uint_as_float(__float_as_uint(a) ^ signbit); }
+
+struct RayState
+{
+  float ox, oy, oz, tnear;
+  float dx, dy, dz;
+  float tfar;
+  // hit
+  float ngx, ngy, ngz, u, v;
+  uint32_t primID, geomID;
+  bool hit;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// per-ray node-test constants
+// ---------------------------------------------------------------------------------------------------
+template <bool ROBUST> struct TravRay;
+
+template <> struct TravRay<true> // node_intersector1.h:108-129
+{
+  float ox, oy, oz;
+  float rnx, rny, rnz; // rdir_near
+  float rfx, rfy, rfz; // rdir_far
+  bool negx, negy, negz;
+  float tnear;
+  __device__ __forceinline__ void init(const RayState& r)
+  {
+    const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f; // 1+3*FLT_EPSILON
+    ox = r.ox; oy = r.oy; oz = r.oz;
+    // zero_fix: |d| < 1e-18 -> +1e-18 (vec3fa.h:163-165), then a true division
+    const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx;
+    const float zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy;
+    const float zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
+    rnx = 1.0f / zx; rny = 1.0f / zy; rnz = 1.0f / zz;
+    rfx = rnx * ulp3; rfy = rny * ulp3; rfz = rnz * ulp3;
+    negx = !(rnx >= 0.0f); negy = !(rny >= 0.0f); negz = !(rnz >= 0.0f);
+    tnear = fmaxf(r.tnear, 0.0f);
+  }
+  __device__ __forceinline__ float nearT(float px, float py, float pz) const
+  {
+    return fmaxf(fmaxf((px - ox) * rnx, (py - oy) * rny), (pz - oz) * rnz);
+  }
+  __device__ __forceinline__ float farT(float px, float py, float pz) const
+  {
+    return fminf(fminf((px - ox) * rfx, (py - oy) * rfy), (pz - oz) * rfz);
+  }
+};
+
+template <> struct TravRay<false> // node_intersector1.h:33-57, AVX2 form with org_rdir
+{
+  float rx, ry, rz;    // rdir = rcp_safe(dir)
+  float orx, ory, orz; // org*rdir
+  bool negx, negy, negz;
+  float tnear;
+  __device__ __forceinline__ void init(const RayState& r)
+  {
+    const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx;
+    const float zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy;
+    const float zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
+    rx = 1.0f / zx; ry = 1.0f / zy; rz = 1.0f / zz; // reference: rcpps + one Newton step (vec3fa.h:133-168)
+    orx = r.ox * rx; ory = r.oy * ry; orz = r.oz * rz;
+    negx = !(rx >= 0.0f); negy = !(ry >= 0.0f); negz = !(rz >= 0.0f);
+    tnear = fmaxf(r.tnear, 0.0f);
+  }
+  __device__ __forceinline__ float nearT(float px, float py, float pz) const
+  {
+    return fmaxf(fmaxf(msub(px, rx, orx), msub(py, ry, ory)), msub(pz, rz, orz));
+  }
+  __device__ __forceinline__ float farT(float px, float py, float pz) const
+  {
+    return fminf(fminf(msub(px, rx, orx), msub(py, ry, ory)), msub(pz, rz, orz));
+  }
+};
+
+__device__ __forceinline__ float q2f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); } // v_cvt_f32_ubyteK
+
+// ---------------------------------------------------------------------------------------------------
+// triangle tests on one record; they return the un-finalized hit like PlueckerHitM / MoellerTrumboreHitM
+// ---------------------------------------------------------------------------------------------------
+struct TriHit
+{
+  float t, u, v, ngx, ngy, ngz;
+};
+
+// Pluecker, watertight, no backface culling (triangle_intersector_pluecker.h:79-132).
+__device__ __forceinline__ bool pluecker(const RayState& r, const float4 A, const float4 B, const float4 C, float tfarBlock, TriHit& h)
+{
+  const float v0x = A.x - r.ox, v0y = A.y - r.oy, v0z = A.z - r.oz;
+  const float v1x = B.x - r.ox, v1y = B.y - r.oy, v1z = B.z - r.oz;
+  const float v2x = C.x - r.ox, v2y = C.y - r.oy, v2z = C.z - r.oz;
+  const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
+  const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
+  const float e2x = v1x - v2x, e2y = v1y - v2y, e2z = v1z - v2z;
+  // U = dot(cross(e0, v2+v0), D) ; cross(a,b) = (msub(a.y,b.z,a.z*b.y), msub(a.z,b.x,a.x*b.z), msub(a.x,b.y,a.y*b.x))
+  float sx = v2x + v0x, sy = v2y + v0y, sz = v2z + v0z;
+  const float U = dot3(msub(e0y, sz, e0z * sy), msub(e0z, sx, e0x * sz), msub(e0x, sy, e0y * sx), r.dx, r.dy, r.dz);
+  sx = v0x + v1x; sy = v0y + v1y; sz = v0z + v1z;
+  const float V = dot3(msub(e1y, sz, e1z * sy), msub(e1z, sx, e1x * sz), msub(e1x, sy, e1y * sx), r.dx, r.dy, r.dz);
+  sx = v1x + v2x; sy = v1y + v2y; sz = v1z + v2z;
+  const float W = dot3(msub(e2y, sz, e2z * sy), msub(e2z, sx, e2x * sz), msub(e2x, sy, e2y * sx), r.dx, r.dy, r.dz);
+  const float minUVW = fminf(fminf(U, V), W);
+  const float maxUVW = fmaxf(fmaxf(U, V), W);
+  if (!((minUVW >= 0.0f) | (maxUVW <= 0.0f))) return false;
+
+  // Ng = stable_triangle_normal(e0,e1,e2) (vec3.h:200-212)
+  const float ab_x = e0z * e1y, ab_y = e0x * e1z, ab_z = e0y * e1x;
+  const float bc_x = e1z * e2y, bc_y = e1x * e2z, bc_z = e1y * e2x;
+  const float cab_x = msub(e0y, e1z, ab_x), cab_y = msub(e0z, e1x, ab_y), cab_z = msub(e0x, e1y, ab_z);
+  const float cbc_x = msub(e1y, e2z, bc_x), cbc_y = msub(e1z, e2x, bc_y), cbc_z = msub(e1x, e2y, bc_z);
+  const float ngx = fabsf(ab_x) < fabsf(bc_x) ? cab_x : cbc_x;
+  const float ngy = fabsf(ab_y) < fabsf(bc_y) ? cab_y : cbc_y;
+  const float ngz = fabsf(ab_z) < fabsf(bc_z) ? cab_z : cbc_z;
+  const float dn = dot3(ngx, ngy, ngz, r.dx, r.dy, r.dz);
+  const float den = dn + dn; // twice()
+  const float absDen = fabsf(den);
+  const uint32_t sgnDen = __float_as_uint(den) & 0x80000000u;
+
+  const float tn = dot3(v0x, v0y, v0z, ngx, ngy, ngz);
+  const float T = tn + tn;
+  const float Ts = xorf(T, sgnDen);
+  if (!(absDen * r.tnear < Ts)) return false;
+  if (!(Ts <= absDen * tfarBlock)) return false;
+  if (!(den != 0.0f)) return false;
+
+  // finalize (:41-51): reference uses rcp = rcpps + Newton step; a correctly rounded division is used here
+  const float rcpDen = 1.0f / den;
+  h.t = T * rcpDen;
+  const float UVW = U + V + W;
+  const float rcpUVW = fabsf(UVW) < 1e-18f ? 0.0f : 1.0f / UVW;
+  h.u = U * rcpUVW;
+  h.v = V * rcpUVW;
+  h.ngx = ngx; h.ngy = ngy; h.ngz = ngz;
+  return true;
+}
+
+// Moeller-Trumbore on (v0, e1=v0-v1, e2=v2-v0) (triangle_intersector_moeller.h:75-113,120-123).
+__device__ __forceinline__ bool moeller(const RayState& r, const float4 A, const float4 B, const float4 C, float tfarBlock, TriHit& h)
+{
+  // Ng = cross(e2, e1)
+  const float ngx = msub(C.y, B.z, C.z * B.y), ngy = msub(C.z, B.x, C.x * B.z), ngz = msub(C.x, B.y, C.y * B.x);
+  const float cx = A.x - r.ox, cy = A.y - r.oy, cz = A.z - r.oz;
+  // R = cross(C, D)
+  const float rx = msub(cy, r.dz, cz * r.dy), ry = msub(cz, r.dx, cx * r.dz), rz = msub(cx, r.dy, cy * r.dx);
+  const float den = dot3(ngx, ngy, ngz, r.dx, r.dy, r.dz);
+  const float absDen = fabsf(den);
+  const uint32_t sgnDen = __float_as_uint(den) & 0x80000000u;
+  const float U = xorf(dot3(rx, ry, rz, C.x, C.y, C.z), sgnDen);
+  const float V = xorf(dot3(rx, ry, rz, B.x, B.y, B.z), sgnDen);
+  if (!((den != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= absDen))) return false;
+  const float T = xorf(dot3(ngx, ngy, ngz, cx, cy, cz), sgnDen);
+  if (!((absDen * r.tnear < T) & (T <= absDen * tfarBlock))) return false;
+  const float rcpAbsDen = 1.0f / absDen;
+  h.t = T * rcpAbsDen;
+  h.u = U * rcpAbsDen;
+  h.v = V * rcpAbsDen;
+  h.ngx = ngx; h.ngy = ngy; h.ngz = ngz;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ray record I/O.  RTCRayHit: [org.xyz tnear][dir.xyz time][tfar mask id flags][Ng.xyz u][v primID geomID instID]
+// ---------------------------------------------------------------------------------------------------
+template <bool VEC> __device__ __forceinline__ void load_ray(const char* p, RayState& r)
+{
+  if (VEC) {
+    const float4 a = ((const float4*)p)[0];
+    const float4 b = ((const float4*)p)[1];
+    const float c = ((const float*)p)[8];
+    r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tnear = a.w;
+    r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tfar = c;
+  } else {
+    const float* f = (const float*)p;
+    r.ox = f[0]; r.oy = f[1]; r.oz = f[2]; r.tnear = f[3];
+    r.dx = f[4]; r.dy = f[5]; r.dz = f[6]; r.tfar = f[8];
+  }
+}
+
+template <bool VEC> __device__ __forceinline__ void store_hit(char* p, const RayState& r, uint32_t instID)
+{
+  ((float*)p)[8] = r.tfar;
+  if (VEC) {
+    ((float4*)p)[3] = make_float4(r.ngx, r.ngy, r.ngz, r.u);
+    ((float4*)p)[4] = make_float4(r.v, __uint_as_float(r.primID), __uint_as_float(r.geomID), __uint_as_float(instID));
+  } else {
+    float* f = (float*)p;
+    uint32_t* w = (uint32_t*)p;
+    f[12] = r.ngx; f[13] = r.ngy; f[14] = r.ngz; f[15] = r.u; f[16] = r.v;
+    w[17] = r.primID; w[18] = r.geomID; w[19] = instID;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// the traversal skeleton
+// ---------------------------------------------------------------------------------------------------
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
+__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK])
+{
+  const uint32_t tid = threadIdx.x;
+  const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
+  const uint32_t gstride = gridDim.x * TRACE_BLOCK;
+  uint2* __restrict__ spill = (uint2*)P.spill + (size_t)gthread * P.spillDepth;
+  const QNode8* __restrict__ nodes = P.accel.nodes;
+
+  WorkCounters wc;
+
+  for (uint32_t i = gthread; i < P.count; i += gstride) {
+    char* rp = (char*)P.rays + (size_t)i * P.stride;
+    RayState r;
+    load_ray<VEC>(rp, r);
+    r.hit = false;
+    // stream front-end: rays with tnear > tfar are skipped (bvh_intersector_stream_filters.cpp:156);
+    // occluded: already-occluded rays return early (bvh_intersector1.cpp:132-134)
+    bool active = r.tnear <= r.tfar;
+    if (OCCLUDED) active = active && !(r.tfar < 0.0f);
+    if (P.accel.root == REF_EMPTY) active = false;
+    if (!active) continue;
+    if (COUNT) wc.rays++;
+
+    TravRay<ROBUST> tr;
+    tr.init(r);
+    float travFar = fmaxf(r.tfar, 0.0f); // tray.tfar
+
+    uint32_t sp = 0; // number of stacked entries
+    uint32_t cur = P.accel.root;
+    bool done = false;
+
+    auto push = [&](uint32_t ref, uint32_t dist, uint32_t slot) {
+      if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
+      else {
+        if (slot - TRACE_LDS_STACK < P.spillDepth) spill[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
+        if (COUNT) wc.spills++;
+      }
+    };
+    auto pop = [&](uint32_t slot) -> uint2 {
+      if (slot < (uint32_t)TRACE_LDS_STACK) return ldsStack[slot][tid];
+      return (slot - TRACE_LDS_STACK < P.spillDepth) ? spill[slot - TRACE_LDS_STACK] : make_uint2(REF_EMPTY, 0x7f800000u);
+    };
+
+    while (!done) {
+      // ---- down traversal ------------------------------------------------------------------------
+      bool popNext = false;
+      while (!(cur & REF_LEAF)) {
+        if (COUNT) wc.nodes++;
+        const uint4* np = (const uint4*)(nodes + cur);
+        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4], n5 = np[5];
+        const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+        const float sx = __uint_as_float((n0.w & 0xffu) << 23);
+        const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
+        const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+        // near / far plane bytes per axis: words .x,.y = lower[0..7], .z,.w = upper[0..7]
+        const uint32_t nx0 = tr.negx ? n3.z : n3.x, nx1 = tr.negx ? n3.w : n3.y;
+        const uint32_t fx0 = tr.negx ? n3.x : n3.z, fx1 = tr.negx ? n3.y : n3.w;
+        const uint32_t ny0 = tr.negy ? n4.z : n4.x, ny1 = tr.negy ? n4.w : n4.y;
+        const uint32_t fy0 = tr.negy ? n4.x : n4.z, fy1 = tr.negy ? n4.y : n4.w;
+        const uint32_t nz0 = tr.negz ? n5.z : n5.x, nz1 = tr.negz ? n5.w : n5.y;
+        const uint32_t fz0 = tr.negz ? n5.x : n5.z, fz1 = tr.negz ? n5.y : n5.w;
+        const uint32_t cref[8] = {n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+
+        uint32_t dist[8];
+        uint32_t mask = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int kk = k & 3;
+          const float npx = madd(q2f(k < 4 ? nx0 : nx1, kk), sx, ox);
+          const float npy = madd(q2f(k < 4 ? ny0 : ny1, kk), sy, oy);
+          const float npz = madd(q2f(k < 4 ? nz0 : nz1, kk), sz, oz);
+          const float fpx = madd(q2f(k < 4 ? fx0 : fx1, kk), sx, ox);
+          const float fpy = madd(q2f(k < 4 ? fy0 : fy1, kk), sy, oy);
+          const float fpz = madd(q2f(k < 4 ? fz0 : fz1, kk), sz, oz);
+          const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
+          const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
+          const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
+          dist[k] = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+          mask |= h ? (1u << k) : 0u;
+        }
+        if (mask == 0) { popNext = true; break; }
+
+        const int nhit = __popc(mask);
+        if (nhit == 1) {
+          const int k = __ffs(mask) - 1;
+          uint32_t c = cref[0];
+#pragma unroll
+          for (int j = 1; j < 8; j++) c = (k == j) ? cref[j] : c;
+          cur = c;
+          continue;
+        }
+        if (OCCLUDED) {
+          // traverseAnyHit (bvh_traverser1.h:638-666): descend into the highest-index hit child, stack the rest
+          // in ascending index order, no sorting.
+          uint32_t slot = sp;
+          uint32_t last = REF_EMPTY;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            if (mask & (1u << k)) {
+              if (last != REF_EMPTY) { push(last, 0u, slot); slot++; }
+              last = cref[k];
+            }
+          }
+          sp = slot;
+          cur = last;
+          continue;
+        }
+        // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
+        // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80).  rank[k] = #children visited before k.
+        uint32_t rank[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) rank[k] = 0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+#pragma unroll
+          for (int b = a + 1; b < 8; b++) {
+            const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u; // tie -> b (higher index) first
+            rank[b] += aFirst;
+            rank[a] += 1u - aFirst;
+          }
+        }
+        // non-hit children carry 0xFFFFFFFF and sort behind every hit child (among themselves irrelevant)
+        const uint32_t base = sp + (uint32_t)nhit - 1u;
+        uint32_t next = REF_EMPTY;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (mask & (1u << k)) {
+            if (rank[k] == 0) next = cref[k];
+            else push(cref[k], dist[k], base - rank[k]);
+          }
+        }
+        sp = base;
+        cur = next;
+      }
+
+      // ---- leaf ------------------------------------------------------------------------------------
+      if (!popNext) {
+        if (COUNT) wc.leaves++;
+        if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
+          r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
+          r.hit = true;
+          break;
+        }
+        travFar = r.tfar; // tray.tfar = ray.tfar (bvh_intersector1.cpp:117)
+      }
+
+      // ---- pop ---------------------------------------------------------------------------------------
+      for (;;) {
+        if (sp == 0) { done = true; break; }
+        sp--;
+        const uint2 e = pop(sp);
+        if (e.x == REF_EMPTY) continue;                           // entry lost to an exhausted spill area
+        if (!OCCLUDED && __uint_as_float(e.y) > r.tfar) continue; // bvh_intersector1.cpp:86
+        cur = e.x;
+        break;
+      }
+    }
+
+    if (r.hit) {
+      if (COUNT) wc.hits++;
+      if (OCCLUDED) ((float*)rp)[8] = r.tfar;
+      else store_hit<VEC>(rp, r, P.instID);
+    }
+  }
+
+  if (COUNT) {
+    TraceCounters* c = P.counters;
+    atomicAdd(&c->rays, wc.rays);
+    atomicAdd(&c->nodeVisits, wc.nodes);
+    atomicAdd(&c->leafVisits, wc.leaves);
+    atomicAdd(&c->primTests, wc.prims);
+    atomicAdd(&c->innerVisits, wc.inner);
+    atomicAdd(&c->hits, wc.hits);
+    atomicAdd(&c->stackSpills, wc.spills);
+  }
+}
+
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(LaunchParams P)
+{
+  __shared__ uint2 ldsStack[TRACE_LDS_STACK][TRACE_BLOCK];
+  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack);
+}
+
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT>
+inline hipError_t launch_vec(const LaunchParams& p, hipStream_t stream)
+{
+  const bool vec = (p.stride % 16 == 0) && (((uintptr_t)p.rays) % 16 == 0);
+  if (vec) hipLaunchKernelGGL((trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, true>), dim3(p.gridBlocks), dim3(TRACE_BLOCK), 0, stream, p);
+  else hipLaunchKernelGGL((trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, false>), dim3(p.gridBlocks), dim3(TRACE_BLOCK), 0, stream, p);
+  return hipGetLastError();
+}
+
+template <typename Leaf, bool ROBUST>
+inline hipError_t launch_leaf(const LaunchParams& p, hipStream_t stream)
+{
+  const bool cnt = p.counters != nullptr;
+  if (p.occluded) return cnt ? launch_vec<Leaf, ROBUST, true, true>(p, stream) : launch_vec<Leaf, ROBUST, true, false>(p, stream);
+  return cnt ? launch_vec<Leaf, ROBUST, false, true>(p, stream) : launch_vec<Leaf, ROBUST, false, false>(p, stream);
+}
+
+} // namespace dev
+} // namespace rtamd

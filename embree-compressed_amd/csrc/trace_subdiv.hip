@@ -1,0 +1,524 @@
+// Subdivision-surface leaves of the quantized BVH8 on gfx950:
+//   GridCellLeaf   eager path: one 3x3-vertex cell = 8 Pluecker triangles with patch-uv mapping
+//                  (kernels/geometry/grid_soa_intersector1.h:44-117, Gather3x3 grid_soa.h:198-245, MapUV :137-156,
+//                   decodeUV :248-257, Intersect1EpilogMU intersector_epilog.h:460-530)
+//   CbvhLeaf<MODE> fork path: traversal of one compressed per-sub-grid BVH blob
+//                  (kernels/geometry/compressed.h:454-752, node decode compressed_node.h:488-510,
+//                   helpers compressed_help.h:86-308, leaf z decode compressed_leaf.h:93-111)
+// The cBVH's implicit complete quadtree has a compile-time depth C here (the kernel is instantiated per C), so its
+// depth-first, nearest-first traversal is a chain of C nested loops that keeps every level's parent box in registers
+// instead of the reference's 16-entry box stack.  The visiting order is the reference's: ascending uint(tNear),
+// equal distances -> lower child index first (compressed.h:690-749); cells use the tNear/tFar of the node decode
+// that produced them (compressed.h:544-549,617); the traversal ray's tfar is never tightened (compressed.h:523).
+// Scalar arithmetic of the fork is written without fused operations (the reference leaves contraction to its
+// compiler; this path is "parity unpinned").
+#include "trace_common.hip.h"
+
+namespace rtamd {
+namespace dev {
+
+// ---------------------------------------------------------------------------------------------------
+// eager: grid cell
+// ---------------------------------------------------------------------------------------------------
+struct RelV
+{
+  float x, y, z;
+};
+
+// Pluecker on vertices already relative to the ray origin; returns un-mapped barycentrics.
+__device__ __forceinline__ bool pluecker_rel(const RayState& r, const RelV a, const RelV b, const RelV c, float tfarBlock, TriHit& h)
+{
+  const float e0x = c.x - a.x, e0y = c.y - a.y, e0z = c.z - a.z;
+  const float e1x = a.x - b.x, e1y = a.y - b.y, e1z = a.z - b.z;
+  const float e2x = b.x - c.x, e2y = b.y - c.y, e2z = b.z - c.z;
+  float sx = c.x + a.x, sy = c.y + a.y, sz = c.z + a.z;
+  const float U = dot3(msub(e0y, sz, e0z * sy), msub(e0z, sx, e0x * sz), msub(e0x, sy, e0y * sx), r.dx, r.dy, r.dz);
+  sx = a.x + b.x; sy = a.y + b.y; sz = a.z + b.z;
+  const float V = dot3(msub(e1y, sz, e1z * sy), msub(e1z, sx, e1x * sz), msub(e1x, sy, e1y * sx), r.dx, r.dy, r.dz);
+  sx = b.x + c.x; sy = b.y + c.y; sz = b.z + c.z;
+  const float W = dot3(msub(e2y, sz, e2z * sy), msub(e2z, sx, e2x * sz), msub(e2x, sy, e2y * sx), r.dx, r.dy, r.dz);
+  const float minUVW = fminf(fminf(U, V), W);
+  const float maxUVW = fmaxf(fmaxf(U, V), W);
+  if (!((minUVW >= 0.0f) | (maxUVW <= 0.0f))) return false;
+  const float ab_x = e0z * e1y, ab_y = e0x * e1z, ab_z = e0y * e1x;
+  const float bc_x = e1z * e2y, bc_y = e1x * e2z, bc_z = e1y * e2x;
+  const float cab_x = msub(e0y, e1z, ab_x), cab_y = msub(e0z, e1x, ab_y), cab_z = msub(e0x, e1y, ab_z);
+  const float cbc_x = msub(e1y, e2z, bc_x), cbc_y = msub(e1z, e2x, bc_y), cbc_z = msub(e1x, e2y, bc_z);
+  const float ngx = fabsf(ab_x) < fabsf(bc_x) ? cab_x : cbc_x;
+  const float ngy = fabsf(ab_y) < fabsf(bc_y) ? cab_y : cbc_y;
+  const float ngz = fabsf(ab_z) < fabsf(bc_z) ? cab_z : cbc_z;
+  const float dn = dot3(ngx, ngy, ngz, r.dx, r.dy, r.dz);
+  const float den = dn + dn;
+  const float absDen = fabsf(den);
+  const uint32_t sgnDen = __float_as_uint(den) & 0x80000000u;
+  const float tn = dot3(a.x, a.y, a.z, ngx, ngy, ngz);
+  const float T = tn + tn;
+  const float Ts = xorf(T, sgnDen);
+  if (!(absDen * r.tnear < Ts)) return false;
+  if (!(Ts <= absDen * tfarBlock)) return false;
+  if (!(den != 0.0f)) return false;
+  const float rcpDen = 1.0f / den;
+  h.t = T * rcpDen;
+  const float UVW = U + V + W;
+  const float rcpUVW = fabsf(UVW) < 1e-18f ? 0.0f : 1.0f / UVW;
+  h.u = U * rcpUVW;
+  h.v = V * rcpUVW;
+  h.ngx = ngx; h.ngy = ngy; h.ngz = ngz;
+  return true;
+}
+
+struct GridCellLeaf
+{
+  template <bool OCCLUDED, bool COUNT>
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
+  {
+    const uint32_t idx = ref & 0x7FFFFFFFu;
+    const float4* gp = (const float4*)(P.accel.blobs + (size_t)idx * sizeof(GridCell));
+    float f[40];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      const float4 q = gp[k];
+      f[4 * k] = q.x; f[4 * k + 1] = q.y; f[4 * k + 2] = q.z; f[4 * k + 3] = q.w;
+    }
+    if (COUNT) wc.prims++;
+    // f[0..8] px, f[9..17] py, f[18..26] pz, f[27..35] packed uv, f[36] geomID, f[37] primID
+    RelV p[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[k] = RelV{f[k] - r.ox, f[9 + k] - r.oy, f[18 + k] - r.oz};
+    // Gather3x3 lane -> (v0,v1,v2) vertex indices r*3+c (grid_soa.h:218-223)
+    constexpr int T0[8] = {0, 3, 1, 4, 3, 6, 4, 7};
+    constexpr int T1[8] = {1, 1, 2, 2, 4, 4, 5, 5};
+    constexpr int T2[8] = {3, 4, 4, 5, 6, 7, 7, 8};
+    const float tfarBlock = r.tfar;
+    bool found = false;
+    TriHit best;
+    best.t = RT_INF;
+    int bestLane = 0;
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+      if (COUNT) wc.inner++;
+      TriHit h;
+      if (pluecker_rel(r, p[T0[l]], p[T1[l]], p[T2[l]], tfarBlock, h)) {
+        if (OCCLUDED) return true;
+        if (!found || h.t < best.t) { // select_min: lowest lane among equal minima
+          best = h;
+          bestLane = l;
+          found = true;
+        }
+      }
+    }
+    if (found) {
+      // MapUV (grid_soa.h:148-155): uv = u*uv1 + v*uv2 + (1-u-v)*uv0 on the 16-bit decoded vertex uvs
+      uint32_t w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+      for (int l = 0; l < 8; l++)
+        if (l == bestLane) {
+          w0 = __float_as_uint(f[27 + T0[l]]);
+          w1 = __float_as_uint(f[27 + T1[l]]);
+          w2 = __float_as_uint(f[27 + T2[l]]);
+        }
+      const float s = 8.0f / 0x10000;
+      const float u0 = (float)(w0 & 0xffffu) * s, v0 = (float)(w0 >> 16) * s;
+      const float u1 = (float)(w1 & 0xffffu) * s, v1 = (float)(w1 >> 16) * s;
+      const float u2 = (float)(w2 & 0xffffu) * s, v2 = (float)(w2 >> 16) * s;
+      const float bu = best.u, bv = best.v;
+      const float bw = (1.0f - bu) - bv;
+      r.u = (bu * u1 + bv * u2) + bw * u0;
+      r.v = (bu * v1 + bv * v2) + bw * v0;
+      r.tfar = best.t;
+      r.ngx = best.ngx; r.ngy = best.ngy; r.ngz = best.ngz;
+      r.geomID = __float_as_uint(f[36]);
+      r.primID = __float_as_uint(f[37]);
+      r.hit = true;
+    }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// fork: cBVH blob
+// ---------------------------------------------------------------------------------------------------
+enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2 };
+
+__constant__ float c_tblBorder[8] = {0.000f, 0.005f, 0.010f, 0.050f, 0.100f, 0.200f, 0.400f, 0.600f};
+__constant__ float c_tblMid[8] = {0.00f, 0.40f, 0.48f, 0.49f, 0.50f, 0.51f, 0.52f, 0.60f};
+
+__device__ __forceinline__ uint32_t compact1by1(uint32_t x)
+{
+  x &= 0x55555555u;
+  x = (x ^ (x >> 1)) & 0x33333333u;
+  x = (x ^ (x >> 2)) & 0x0f0f0f0fu;
+  x = (x ^ (x >> 4)) & 0x00ff00ffu;
+  x = (x ^ (x >> 8)) & 0x0000ffffu;
+  return x;
+}
+
+struct CbvhCtx
+{
+  const CbvhHeader* H;
+  const uint32_t* nodes;
+  const uint8_t* leaves;
+  const float* grid;
+  RayState* r;
+  uint32_t elems;
+  // projected ray (compressed.h:470-508) and its robust TravRay<4,4,true> constants (:522-523)
+  float ox, oy, oz, dx, dy, dz;
+  float rnx, rny, rnz, rfx, rfy, rfz;
+  bool negx, negy, negz;
+  float travFar; // travRay.tfar: fixed for the whole blob
+  float tfar;    // local tfar, shrinks with hits
+  float near, zFactor;
+  bool special;
+  float lox, loy, loz; // lOrg
+  float rcp_edges, extent;
+};
+
+__device__ __forceinline__ void project3(const float* m, float x, float y, float z, float& ox, float& oy, float& oz)
+{
+  const float px = (m[0] * x + m[1] * y) + m[2];
+  const float py = (m[3] * x + m[4] * y) + m[5];
+  const float pw = (m[6] * x + m[7] * y) + m[8];
+  ox = px / pw; oy = py / pw; oz = z;
+}
+
+// 2-D line intersection, compressed_help.h:93-106
+__device__ __forceinline__ float intersect_line(float p2x, float p2y, float p3x, float p3y, float ox, float oy, float dx, float dy)
+{
+  const float vx = p2x - ox, vy = p2y - oy;
+  const float lx = p3x - p2x, ly = p3y - p2y;
+  const float t1 = (ly * vx - lx * vy) / (ly * dx - lx * dy);
+  const float t2 = (dx * vy - dy * vx) / (lx * dy - ly * dx);
+  return (t2 >= 0.f && t2 <= 1.f) ? t1 : __builtin_nanf("");
+}
+
+// commit a hit found inside the blob (compressed.h:570-591 / :631-653)
+__device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float t)
+{
+  RayState& r = *c.r;
+  const CbvhHeader* H = c.H;
+  r.u = H->uv0x + u * H->uv1x;
+  r.v = H->uv0y + v * H->uv1y;
+  r.ngx = 1.f; r.ngy = 0.f; r.ngz = 0.f; // dummy normal
+  r.geomID = H->geomID;
+  r.primID = H->primID;
+  r.hit = true;
+  c.tfar = t;
+  if (c.special) {
+    // flat frame: un-project the local hit point and measure the distance in the rotated world frame (:583-587)
+    float px, py, pz;
+    project3(H->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
+    const float ex = px - c.lox, ey = py - c.loy, ez = pz - c.loz;
+    r.tfar = sqrtf(madd(ex, ex, madd(ey, ey, ez * ez)));
+  } else
+    r.tfar = t / c.zFactor + c.near;
+}
+
+// intersect_patch, compressed_help.h:135-229
+__device__ __forceinline__ bool intersect_patch(uint32_t idx, float rcp_edges, float dz, float t1, float t2, float v0, float v1, float v2,
+                                                float v3, float blx, float bly, float bhx, float bhy, const CbvhCtx& c, float& u, float& v,
+                                                float& tt)
+{
+  const float px = t1 * c.dx + c.ox, py = t1 * c.dy + c.oy, pz = t1 * c.dz + c.oz;
+  const float p2x = t2 * c.dx + c.ox, p2y = t2 * c.dy + c.oy, p2z = t2 * c.dz + c.oz;
+  const float lenX = 1.0f / (bhx - blx), lenY = 1.0f / (bhy - bly); // reference: rcp()
+  const float fx1 = (px - blx) * lenX, fy1 = (py - bly) * lenY;
+  const float mx = (float)compact1by1(idx), my = (float)compact1by1(idx >> 1);
+  if (t2 - t1 < 1.0E-6f) { // too small a patch
+    tt = t1;
+    u = (fx1 + mx) * rcp_edges;
+    v = (fy1 + my) * rcp_edges;
+    return true;
+  }
+  const float fx2 = (p2x - blx) * lenX, fy2 = (p2y - bly) * lenY;
+  const float dx1 = 1.f - fx1, dy1 = 1.f - fy1;
+  float z1 = v0 * dx1 * dy1 + v1 * fx1 * dy1 + v2 * dx1 * fy1 + v3 * fx1 * fy1;
+  const float dx2 = 1.f - fx2, dy2 = 1.f - fy2;
+  float z2 = v0 * dx2 * dy2 + v1 * fx2 * dy2 + v2 * dx2 * fy2 + v3 * fx2 * fy2;
+  if (pz >= z1 && pz <= z1 + dz) { // entry point inside the slab
+    tt = t1;
+    u = (fx1 + mx) * rcp_edges;
+    v = (fy1 + my) * rcp_edges;
+    return true;
+  }
+  if (pz > z1 + dz) { z1 += dz; z2 += dz; }
+  const float alpha = p2z - z2, beta = z1 - pz;
+  const float t = (t1 * alpha + t2 * beta) / (alpha + beta);
+  const float d = (t - t1) / (t2 - t1);
+  const float fx = fx2 - fx1, fy = fy2 - fy1;
+  if (t < tt && t >= t1 && t <= t2) {
+    u = (fx * d + fx1 + mx) * rcp_edges;
+    v = (fy * d + fy1 + my) * rcp_edges;
+    tt = t;
+    return true;
+  }
+  return false;
+}
+
+// intersect_triangle, compressed_help.h:232-275 (world space, updates the ray in place)
+__device__ __forceinline__ bool grid_triangle(const float* v0, const float* v1, const float* v2, RayState& r)
+{
+  const float a = v0[0] - v1[0], b = v0[1] - v1[1], cc = v0[2] - v1[2];
+  const float d = v0[0] - v2[0], e = v0[1] - v2[1], f = v0[2] - v2[2];
+  const float g = r.dx, h = r.dy, i = r.dz;
+  const float j = v0[0] - r.ox, k = v0[1] - r.oy, l = v0[2] - r.oz;
+  float common1 = e * i - h * f, common2 = g * f - d * i, common3 = d * h - e * g;
+  const float M = 1.0f / (a * common1 + b * common2 + cc * common3); // reference: rcp()
+  float beta = j * common1 + k * common2 + l * common3;
+  common1 = a * k - j * b; common2 = j * cc - a * l; common3 = b * l - k * cc;
+  float gamma = i * common1 + h * common2 + g * common3;
+  float tt = -(f * common1 + e * common2 + d * common3);
+  beta *= M; gamma *= M; tt *= M;
+  if (tt > 0 && tt < r.tfar && tt >= r.tnear)
+    if (beta > 0 && gamma > 0 && beta + gamma <= 1) {
+      r.tfar = tt;
+      r.u = beta;
+      r.v = gamma;
+      return true;
+    }
+  return false;
+}
+
+template <int MODE, bool COUNT>
+__device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, float tN, float tF, float blx, float bly, float blz, float bhx,
+                                          float bhy, float bhz, WorkCounters& wc)
+{
+  if (MODE == MODE_LEAF) { // compressed.h:539-593
+    if (tN >= c.tfar) return;
+    const float dimZ = bhz - blz;
+    const float range = (1.f + 2.f * c.extent) * dimZ;
+    const float dz = 0.0625f * range; // getDelta() = rcp(16) (compressed_leaf.h:109-111)
+    const float rcpF = 0.0625f * range;
+    const float off = blz - dimZ * c.extent;
+    const uint32_t z12 = c.leaves[2 * idx], z34 = c.leaves[2 * idx + 1];
+    const float z1 = off + rcpF * (float)(z12 >> 4), z2 = off + rcpF * (float)(z12 & 0xf);
+    const float z3 = off + rcpF * (float)(z34 >> 4), z4 = off + rcpF * (float)(z34 & 0xf);
+    float u, v, t = c.tfar;
+    if (COUNT) wc.inner++;
+    if (intersect_patch(idx, c.rcp_edges, dz, tN, tF, z1, z2, z3, z4, blx, bly, bhx, bhy, c, u, v, t)) cbvh_commit(c, u, v, t);
+  } else if (MODE == MODE_GRID) { // compressed.h:597-611, compressed_help.h:278-308
+    const uint32_t x = compact1by1(idx), y = compact1by1(idx >> 1);
+    const uint32_t w = c.H->grid_width;
+    const float* g0 = c.grid + 3 * (y * w + x);
+    const float* g1 = g0 + 3;
+    const float* g2 = g0 + 3 * w;
+    const float* g3 = g2 + 3;
+    const float q0[3] = {g0[0], g0[1], g0[2]}, q1[3] = {g1[0], g1[1], g1[2]}, q2[3] = {g2[0], g2[1], g2[2]}, q3[3] = {g3[0], g3[1], g3[2]};
+    RayState& r = *c.r;
+    if (COUNT) wc.inner++;
+    const bool hit1 = grid_triangle(q0, q1, q2, r);
+    const bool hit2 = grid_triangle(q3, q2, q1, r);
+    if (hit1 || hit2) {
+      const float uu = hit2 ? ((float)x + (1.f - r.u)) * c.rcp_edges : ((float)x + r.u) * c.rcp_edges;
+      const float vv = hit2 ? ((float)y + (1.f - r.v)) * c.rcp_edges : ((float)y + r.v) * c.rcp_edges;
+      r.ngx = 1.f; r.ngy = 0.f; r.ngz = 0.f;
+      r.u = c.H->uv0x + uu * c.H->uv1x;
+      r.v = c.H->uv0y + vv * c.H->uv1y;
+      r.geomID = c.H->geomID;
+      r.primID = c.H->primID;
+      r.hit = true;
+      c.tfar = (r.tfar - c.near) * c.zFactor;
+    }
+  } else { // voxel, compressed.h:614-654
+    const float is = tN;
+    if (is <= c.tfar) {
+      const float u = (((c.ox + c.dx * is) - blx) / (bhx - blx) + (float)compact1by1(idx)) * c.rcp_edges;
+      const float v = (((c.oy + c.dy * is) - bly) / (bhy - bly) + (float)compact1by1(idx >> 1)) * c.rcp_edges;
+      if (COUNT) wc.inner++;
+      cbvh_commit(c, u, v, is);
+    }
+  }
+}
+
+// One inner node with REM levels below it (REM == 1: its children are cells).
+template <int MODE, int REM, bool COUNT>
+__device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, float blx, float bly, float blz, float bhx, float bhy, float bhz,
+                                          WorkCounters& wc)
+{
+  const uint32_t w = c.nodes[curr]; // bytes xz, x, yz, y
+  if (COUNT) wc.inner++;
+  // getNode, compressed_node.h:488-510
+  const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
+  const float lx0 = c_tblBorder[(w >> 5) & 7] * dimX + blx;          // X1: children 0,2 lower
+  const float lx1 = c_tblMid[(w >> 2) & 7] * dimX + blx;             // X2: children 1,3 lower
+  const float ux0 = (1.f - c_tblMid[(w >> 13) & 7]) * dimX + blx;    // X3: children 0,2 upper
+  const float ux1 = (1.f - c_tblBorder[(w >> 10) & 7]) * dimX + blx; // X4: children 1,3 upper
+  const float ly0 = c_tblBorder[(w >> 21) & 7] * dimY + bly;         // Y1: children 0,1 lower
+  const float ly1 = c_tblMid[(w >> 18) & 7] * dimY + bly;            // Y2: children 2,3 lower
+  const float uy0 = (1.f - c_tblMid[(w >> 29) & 7]) * dimY + bly;    // Y3: children 0,1 upper
+  const float uy1 = (1.f - c_tblBorder[(w >> 26) & 7]) * dimY + bly; // Y4: children 2,3 upper
+  const float lz = (float)(w & 3) * 0.25f * dimZ + blz;              // table3 = k/4
+  const float uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
+
+  // intersectNodeRobust (node_intersector1.h:351-368) on the two x columns, two y rows, one z slab
+  const float nX0 = ((c.negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((c.negx ? lx0 : ux0) - c.ox) * c.rfx;
+  const float nX1 = ((c.negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((c.negx ? lx1 : ux1) - c.ox) * c.rfx;
+  const float nY0 = ((c.negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((c.negy ? ly0 : uy0) - c.oy) * c.rfy;
+  const float nY1 = ((c.negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((c.negy ? ly1 : uy1) - c.oy) * c.rfy;
+  const float nZ = ((c.negz ? uz : lz) - c.oz) * c.rnz, fZ = ((c.negz ? lz : uz) - c.oz) * c.rfz;
+  float tN[4], tF[4];
+  uint32_t d[4];
+  uint32_t mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    tN[k] = fmaxf(fmaxf((k & 1) ? nX1 : nX0, (k & 2) ? nY1 : nY0), fmaxf(nZ, 0.f));
+    tF[k] = fminf(fminf((k & 1) ? fX1 : fX0, (k & 2) ? fY1 : fY0), fminf(fZ, c.travFar));
+    const bool h = tN[k] <= tF[k];
+    d[k] = h ? __float_as_uint(tN[k]) : 0xFFFFFFFFu;
+    mask |= h ? (1u << k) : 0u;
+  }
+  if (mask == 0) return;
+  // nearest first, equal distances -> lower index first (compressed.h:690-749)
+  uint32_t rank[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = a + 1; b < 4; b++) {
+      const uint32_t bFirst = d[b] < d[a] ? 1u : 0u; // tie -> a (lower index) first
+      rank[a] += bFirst;
+      rank[b] += 1u - bFirst;
+    }
+  const int nhit = __popc(mask);
+  for (int k = 0; k < nhit; k++) {
+    int rr = 0;
+#pragma unroll
+    for (int q = 1; q < 4; q++) rr = ((mask >> q) & 1u) && rank[q] == (uint32_t)k ? q : rr;
+    if (!(((mask >> rr) & 1u) && rank[rr] == (uint32_t)k)) rr = 0;
+    const float cbx0 = (rr & 1) ? lx1 : lx0, cbx1 = (rr & 1) ? ux1 : ux0;
+    const float cby0 = (rr & 2) ? ly1 : ly0, cby1 = (rr & 2) ? uy1 : uy0;
+    const uint32_t child = 4u * curr + 1u + (uint32_t)rr;
+    if constexpr (REM == 1) {
+      float tn = tN[0], tf = tF[0];
+#pragma unroll
+      for (int q = 1; q < 4; q++) { tn = rr == q ? tN[q] : tn; tf = rr == q ? tF[q] : tf; }
+      cbvh_cell<MODE, COUNT>(c, child - c.elems, tn, tf, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+    } else
+      cbvh_node<MODE, REM - 1, COUNT>(c, child, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+  }
+}
+
+template <int MODE, int LEVELS> struct CbvhLeaf
+{
+  template <bool OCCLUDED, bool COUNT>
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
+  {
+    const uint32_t idx = ref & 0x7FFFFFFFu;
+    const uint8_t* blob = P.accel.blobs + (size_t)idx * P.accel.blobStride;
+    const CbvhHeader* H = (const CbvhHeader*)blob;
+    if (COUNT) wc.prims++;
+    if (OCCLUDED) {
+      // the fork's occluded() is a stub returning true for every leaf the outer traversal reaches
+      // (compressed.h:754-756): the leaf is reached iff the robust slab test of its bounds passes
+      const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx, zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy, zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
+      const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
+      const float rnx = 1.0f / zx, rny = 1.0f / zy, rnz = 1.0f / zz;
+      const float nx = ((rnx >= 0.f ? H->wlo[0] : H->whi[0]) - r.ox) * rnx, fx = ((rnx >= 0.f ? H->whi[0] : H->wlo[0]) - r.ox) * (rnx * ulp3);
+      const float ny = ((rny >= 0.f ? H->wlo[1] : H->whi[1]) - r.oy) * rny, fy = ((rny >= 0.f ? H->whi[1] : H->wlo[1]) - r.oy) * (rny * ulp3);
+      const float nz = ((rnz >= 0.f ? H->wlo[2] : H->whi[2]) - r.oz) * rnz, fz = ((rnz >= 0.f ? H->whi[2] : H->wlo[2]) - r.oz) * (rnz * ulp3);
+      const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, fmaxf(r.tnear, 0.f)));
+      const float tf = fminf(fminf(fx, fy), fminf(fz, fmaxf(r.tfar, 0.f)));
+      return tn <= tf;
+    }
+
+    CbvhCtx c;
+    c.H = H;
+    c.nodes = (const uint32_t*)(blob + CBVH_HEADER_BYTES);
+    c.elems = H->elems;
+    c.leaves = blob + CBVH_HEADER_BYTES + 4u * c.elems;
+    c.grid = (const float*)(blob + CBVH_HEADER_BYTES + 4u * c.elems);
+    c.r = &r;
+    c.rcp_edges = H->rcp_edges;
+    c.extent = H->extent;
+    // rotate the ray into the local frame (:458-459; xfmPoint/xfmVector are fma chains, linearspace3.h:168-169)
+    const float* S = H->space;
+    c.lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
+    c.loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
+    c.loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
+    const float ldx = madd(r.dx, S[0], madd(r.dy, S[1], r.dz * S[2]));
+    const float ldy = madd(r.dx, S[3], madd(r.dy, S[4], r.dz * S[5]));
+    const float ldz = madd(r.dx, S[6], madd(r.dy, S[7], r.dz * S[8]));
+
+    // intersect_frustum, compressed_help.h:109-133
+    float near = r.tnear, far = r.tfar;
+    {
+      const float* B = H->box;
+      const float rz = 1.0f / (fabsf(ldz) < 1e-18f ? 1e-18f : ldz); // rcp_safe
+      const float orz = c.loz * rz;
+      const float t1z = B[0] * rz - orz, t2z = B[1] * rz - orz;
+      const float t1x = intersect_line(B[2], B[3], B[6], B[7], c.lox, c.loy, ldx, ldy);
+      const float t2x = intersect_line(B[4], B[5], B[8], B[9], c.lox, c.loy, ldx, ldy);
+      const float t1y = intersect_line(B[2], B[3], B[4], B[5], c.lox, c.loy, ldx, ldy);
+      const float t2y = intersect_line(B[6], B[7], B[8], B[9], c.lox, c.loy, ldx, ldy);
+      const float near1 = fminf(fminf(t1x, t2x), fminf(t1y, t2y));
+      const float far1 = fmaxf(fmaxf(t1x, t2x), fmaxf(t1y, t2y));
+      near = fmaxf(fmaxf(fminf(t1z, t2z), near1), near);
+      far = fminf(fminf(fmaxf(t1z, t2z), far1), far);
+      if (!(near <= far && near1 == near1 && far1 == far1)) return false;
+    }
+    c.near = near;
+
+    // projected ray between entry and exit point (:470-508)
+    float tx, ty, tz;
+    project3(H->proj, c.lox + ldx * near, c.loy + ldy * near, c.loz + ldz * near, c.ox, c.oy, c.oz);
+    project3(H->proj, c.lox + ldx * far, c.loy + ldy * far, c.loz + ldz * far, tx, ty, tz);
+    c.dx = tx - c.ox; c.dy = ty - c.oy; c.dz = tz - c.oz;
+    c.special = false;
+    c.zFactor = 0.f;
+    const float g_epsilon = 1.0E-4f;
+    if (fabsf(c.dx) < g_epsilon && fabsf(c.dy) < g_epsilon && fabsf(c.dz) < g_epsilon) {
+      c.dz = copysignf(1.f, ldz);
+      c.oz -= c.dz;
+      c.zFactor = 3.402823466e+38f;
+      c.tfar = 3.402823466e+38f;
+    } else if (fabsf(c.dz) < g_epsilon) {
+      c.special = true;
+      const float len2 = madd(c.dx, c.dx, madd(c.dy, c.dy, c.dz * c.dz));
+      c.tfar = sqrtf(len2);
+      const float rl = 1.0f / sqrtf(len2); // reference: rsqrt + Newton step
+      c.dx *= rl; c.dy *= rl; c.dz *= rl;
+    } else {
+      const float len2 = madd(c.dx, c.dx, madd(c.dy, c.dy, c.dz * c.dz));
+      const float rl = 1.0f / sqrtf(len2);
+      c.dx *= rl; c.dy *= rl; c.dz *= rl;
+      c.zFactor = ldz / c.dz;
+      c.tfar = (r.tfar - near) * c.zFactor;
+    }
+    c.travFar = c.tfar;
+    {
+      const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
+      const float zx = fabsf(c.dx) < 1e-18f ? 1e-18f : c.dx, zy = fabsf(c.dy) < 1e-18f ? 1e-18f : c.dy, zz = fabsf(c.dz) < 1e-18f ? 1e-18f : c.dz;
+      c.rnx = 1.0f / zx; c.rny = 1.0f / zy; c.rnz = 1.0f / zz;
+      c.rfx = c.rnx * ulp3; c.rfy = c.rny * ulp3; c.rfz = c.rnz * ulp3;
+      c.negx = !(c.rnx >= 0.f); c.negy = !(c.rny >= 0.f); c.negz = !(c.rnz >= 0.f);
+    }
+    // root: local frame box xy in [-1,1], z from the leaf data (:517-519)
+    cbvh_node<MODE, LEVELS, COUNT>(c, 0u, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);
+    return false;
+  }
+};
+
+template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t stream, uint32_t levels)
+{
+  switch (levels) {
+  case 1: return launch_leaf<CbvhLeaf<MODE, 1>, true>(p, stream);
+  case 2: return launch_leaf<CbvhLeaf<MODE, 2>, true>(p, stream);
+  case 3: return launch_leaf<CbvhLeaf<MODE, 3>, true>(p, stream);
+  case 4: return launch_leaf<CbvhLeaf<MODE, 4>, true>(p, stream);
+  case 5: return launch_leaf<CbvhLeaf<MODE, 5>, true>(p, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+} // namespace dev
+
+hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream)
+{
+  switch (p.accel.kind) {
+  case ACCEL_GRIDSOA: return dev::launch_leaf<dev::GridCellLeaf, true>(p, stream);
+  case ACCEL_CBVH_BOX: return dev::launch_cbvh<dev::MODE_BOX>(p, stream, p.cbvhLevels);
+  case ACCEL_CBVH_LEAF: return dev::launch_cbvh<dev::MODE_LEAF>(p, stream, p.cbvhLevels);
+  case ACCEL_CBVH_GRID: return dev::launch_cbvh<dev::MODE_GRID>(p, stream, p.cbvhLevels);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+} // namespace rtamd

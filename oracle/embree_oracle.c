@@ -92,7 +92,13 @@ struct orc_scene
   oblock* blocks;
   size_t nblocks, capblocks;
   uint32_t root;
+  /* subdivision scenes (oracle_subdiv part below): mode 2 = eager grid cells, 3/4/5 = cBVH box/leaf/grid */
+  uint8_t* blobs;
+  size_t blobStride;
+  unsigned levels;
 };
+static void subdiv_leaf_intersect(const struct orc_scene* s, uint32_t blob, void* rayhit, uint32_t instID);
+static int subdiv_leaf_occluded(const struct orc_scene* s, uint32_t blob, void* rayhit);
 
 /* leaf reference: ORC_LEAF | nblocks<<27 | first block (bvh.h:1472-1482 keeps the block count in the low 4 bits) */
 static inline uint32_t mk_leaf(uint32_t first, uint32_t n) { return ORC_LEAF | (n << 27) | first; }
@@ -141,7 +147,7 @@ static int bin_build(obuild* B, size_t begin, size_t end)
     }
   memcpy(B->bins[me].lo, lo, 12); memcpy(B->bins[me].hi, hi, 12);
   B->bins[me].begin = begin; B->bins[me].end = end; B->bins[me].left = B->bins[me].right = -1;
-  if (end - begin <= 8) return me;
+  if (end - begin <= (B->s->mode >= 2 ? 1u : 8u)) return me; /* subdiv builders: one primitive per leaf (bvh_builder_subdiv.cpp:845-851) */
   int axis = 0;
   if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
   if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
@@ -185,7 +191,7 @@ static uint32_t emit_leaf(obuild* B, size_t begin, size_t end)
 static uint32_t emit_node(obuild* B, int bn)
 {
   const obin* b = &B->bins[bn];
-  if (b->left < 0) return emit_leaf(B, b->begin, b->end);
+  if (b->left < 0) return B->s->mode >= 2 ? mk_leaf(B->prims[b->begin].tri, 1) : emit_leaf(B, b->begin, b->end);
   int kids[8], nk = 0;
   kids[nk++] = b->left; kids[nk++] = b->right;
   while (nk < 8) { /* open the largest inner child */
@@ -258,7 +264,7 @@ orc_scene* orc_scene_new_triangles(const float* verts, size_t nverts, const uint
 void orc_scene_free(orc_scene* s)
 {
   if (!s) return;
-  free(s->nodes); free(s->blocks); free(s);
+  free(s->nodes); free(s->blocks); free(s->blobs); free(s);
 }
 
 /* ------------------------------------------------------------------------------------------------------ */
@@ -535,7 +541,7 @@ static void traverse_any(const onode* n, unsigned mask, uint32_t* cur, uint32_t*
 static void intersect1(const orc_scene* s, orayhit* ray, uint32_t instID)
 {
   if (s->root == ORC_EMPTY) return;
-  const int robust = s->mode == 0;
+  const int robust = s->mode != 1; /* Triangle4v and every subdivision intersector traverse robustly */
   sitem stack[ORC_STACK];
   sitem* sp = stack + 1;
   stack[0].ptr = s->root; stack[0].dist = f2u(-ORC_INF);
@@ -556,6 +562,12 @@ static void intersect1(const orc_scene* s, orayhit* ray, uint32_t instID)
       traverse_closest(n, mask, tNear, &cur, &sp);
     }
     g_cnt[1]++;
+    if (s->mode >= 2) { /* subdivision leaf: a grid cell or a cBVH blob */
+      g_cnt[2]++;
+      subdiv_leaf_intersect(s, cur & 0x07FFFFFFu, ray, instID);
+      tr.tfar = ray->tfar;
+      continue;
+    }
     const uint32_t first = cur & 0x07FFFFFFu, num = (cur >> 27) & 15u;
     for (uint32_t i = 0; i < num; i++) { /* ArrayIntersector1::intersect, intersector_iterators.h:32-36 */
       const oblock* b = &s->blocks[first + i];
@@ -582,7 +594,7 @@ static void occluded1(const orc_scene* s, orayhit* ray)
 {
   if (ray->tfar < 0.0f) return; /* :132-134 */
   if (s->root == ORC_EMPTY) return;
-  const int robust = s->mode == 0;
+  const int robust = s->mode != 1;
   uint32_t stack[ORC_STACK];
   uint32_t* sp = stack + 1;
   stack[0] = s->root;
@@ -599,6 +611,10 @@ static void occluded1(const orc_scene* s, orayhit* ray)
       const unsigned mask = node_test(n, &tr, robust, tNear);
       if (mask == 0) goto pop;
       traverse_any(n, mask, &cur, &sp);
+    }
+    if (s->mode >= 2) {
+      if (subdiv_leaf_occluded(s, cur & 0x07FFFFFFu, ray)) { ray->tfar = -ORC_INF; return; }
+      continue;
     }
     const uint32_t first = cur & 0x07FFFFFFu, num = (cur >> 27) & 15u;
     for (uint32_t i = 0; i < num; i++) {
@@ -716,3 +732,6 @@ void orc_make_random_rays(void* rayhits, uint32_t M, size_t byteStride, const fl
     memcpy((char*)rayhits + (size_t)i * byteStride, &r, 80);
   }
 }
+
+/* subdivision leaves (eager grid cells, fork cBVH blobs) */
+#include "subdiv_oracle.inc"

@@ -97,6 +97,19 @@ class TriangleScene:
             self.handle = None
 
 
+class SubdivScene(TriangleScene):
+    """Scene over leaf records exported by the product (rtcamdGetAccelData kind 2).
+    mode 2: eager grid cells (stride 160); 3/4/5: fork cBVH blobs box/leaf/grid."""
+
+    def __init__(self, blobs, stride, mode, levels=3):
+        self.L = lib()
+        self.L.orc_scene_new_subdiv.restype = C.c_void_p
+        self.L.orc_scene_new_subdiv.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]
+        self.blobs = np.ascontiguousarray(blobs, dtype=np.uint8)
+        assert self.blobs.size % stride == 0
+        self.handle = self.L.orc_scene_new_subdiv(self.blobs.ctypes.data, stride, self.blobs.size // stride, mode, levels)
+
+
 def make_random_rays(m, lo, hi, seed=0, double_eval=False, dtype=None):
     """RTCRayHit records from the drand48-compatible generator of BASELINE.md section 3."""
     from numpy import dtype as _dt  # noqa: F401

@@ -1,0 +1,154 @@
+"""GPU parity tests of the subdivision hot path (rows a11-a17 of SURVEY.md section 8), through the C-ABI.
+
+The product tessellates on the host, encodes eager grid cells / fork cBVH blobs, and traverses them with the HIP
+kernels; the oracle re-traverses the SAME exported leaf records on the CPU with its own BVH and the reference's
+stack-based cBVH loop.  Bar: geomID/primID exact, t/u/v within 1e-4 relative.  Hit-count anchors are the reference
+outputs recorded in SURVEY.md section 6 (eager and compressed.grid: 162 467 of 1 M rays).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import INVALID, compare_hits, fill_rays, random_rays_np
+
+pytestmark = pytest.mark.gpu
+
+ACCELS = {"default": 2, "bvh4.compressed.box": 3, "bvh4.compressed.leaf": 4, "bvh4.compressed.grid": 5}
+
+
+def _build(rtc, accel, verts, fs, fi, L, Cl, extra=None, displacement=None):
+    dev = rtc.Device(f"subdiv_accel={accel}")
+    sc = rtc.Scene(dev)
+    sc.add_subdiv(verts, fs, fi, displacement=displacement)
+    if extra is not None:
+        sc.add_triangles(*extra)
+    sc.set_levels(L, Cl)
+    sc.commit()
+    return dev, sc
+
+
+@pytest.mark.parametrize("accel", list(ACCELS))
+@pytest.mark.parametrize("L,Cl,nrays", [(3, 2, 100_000), (6, 3, 1_000_000)])
+def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
+    verts, fs, fi = bomberman
+    dev, sc = _build(rtc, accel, verts, fs, fi, L, Cl)
+    st = sc.stats()
+    orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
+    lo, hi = verts.min(0), verts.max(0)
+    want = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
+    got = want.copy()
+    orc.intersect1M(want, nthreads=8)
+    sc.intersect1M(got)
+    nh = compare_hits(got, want, what=f"{accel} L{L} C{Cl}")
+    if (L, Cl, nrays) == (6, 3, 1_000_000) and accel in ("default", "bvh4.compressed.grid"):
+        assert nh == 162_467  # reference output, SURVEY.md section 6 (eager GridSOA and compressed.grid)
+    cnt = sc.intersect1M_counted(po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True))
+    assert cnt["hits"] == nh and cnt["stackSpills"] >= 0 and cnt["nodeVisits"] > 0
+    # any-hit
+    occ = rtc.aligned_rays(nrays)
+    src = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
+    for f in occ.dtype.names:
+        occ[f] = src[f]
+    wocc = occ.copy()
+    sc.occluded1M(occ)
+    orc.occluded1M(wocc, nthreads=8)
+    if accel == "default":
+        assert np.array_equal(occ["tfar"], wocc["tfar"])
+        assert np.array_equal(occ["tfar"] == -np.inf, got["geomID"] != INVALID)
+    else:
+        # fork: occluded() is a stub that reports every leaf the outer traversal reaches (compressed.h:754-756);
+        # product and oracle have different outer trees, so grazing rays may differ at rounding level
+        diff = int(((occ["tfar"] == -np.inf) != (wocc["tfar"] == -np.inf)).sum())
+        assert diff <= max(2, nrays // 20000), diff
+        assert np.all((occ["tfar"] == -np.inf)[got["geomID"] != INVALID])
+    orc.free()
+    sc.release()
+    dev.release()
+
+
+def _cube():
+    v = np.array([[-1, -1, -1], [-1, -1, 1], [-1, 1, -1], [-1, 1, 1], [1, -1, -1], [1, -1, 1], [1, 1, -1], [1, 1, 1]], np.float32)
+    # displacement_geometry tutorial cube (tutorials/displacement_geometry/displacement_geometry_device.cpp:31-66)
+    fi = np.array([0, 4, 5, 1, 1, 5, 7, 3, 3, 7, 6, 2, 2, 6, 4, 0, 4, 6, 7, 5, 0, 1, 3, 2], np.uint32)
+    fs = np.full(6, 4, np.uint32)
+    return v, fs, fi
+
+
+class DisplArgs(C.Structure):
+    _fields_ = [("geometryUserPtr", C.c_void_p), ("geometry", C.c_void_p), ("primID", C.c_uint), ("timeStep", C.c_uint),
+                ("u", C.POINTER(C.c_float)), ("v", C.POINTER(C.c_float)),
+                ("Ng_x", C.POINTER(C.c_float)), ("Ng_y", C.POINTER(C.c_float)), ("Ng_z", C.POINTER(C.c_float)),
+                ("P_x", C.POINTER(C.c_float)), ("P_y", C.POINTER(C.c_float)), ("P_z", C.POINTER(C.c_float)), ("N", C.c_uint)]
+
+
+DISPL_CB = C.CFUNCTYPE(None, C.POINTER(DisplArgs))
+
+
+def _displace(argp):
+    a = argp.contents
+    n = a.N
+    P = [np.ctypeslib.as_array(p, shape=(n,)) for p in (a.P_x, a.P_y, a.P_z)]
+    Ng = [np.ctypeslib.as_array(p, shape=(n,)) for p in (a.Ng_x, a.Ng_y, a.Ng_z)]
+    # normals handed to the callback are unit length and point outwards on the cube
+    nn = np.sqrt(Ng[0] ** 2 + Ng[1] ** 2 + Ng[2] ** 2)
+    assert np.all(np.abs(nn - 1) < 1e-4)
+    assert np.all(P[0] * Ng[0] + P[1] * Ng[1] + P[2] * Ng[2] > 0)
+    d = (0.15 * np.abs(np.sin(7 * P[0]) * np.sin(5 * P[1]) * np.sin(9 * P[2]))).astype(np.float32)
+    for k in range(3):
+        P[k] += d * Ng[k]
+
+
+@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf", "bvh4.compressed.box", "bvh4.compressed.grid"])
+def test_displaced_cube_with_ground_plane(rtc, po, accel):
+    """BASELINE config 3 shape: displaced subdivision cube (all corners extraordinary) + triangle ground plane,
+    i.e. two accels traversed one after the other like AccelN (kernels/common/acceln.cpp:51-56)."""
+    v, fs, fi = _cube()
+    gv = np.array([[-10, -2, -10], [-10, -2, 10], [10, -2, -10], [10, -2, 10]], np.float32)
+    gt = np.array([[0, 1, 2], [1, 3, 2]], np.uint32)
+    cb = DISPL_CB(_displace)
+    L, Cl = 5, 4
+    dev = rtc.Device(f"subdiv_accel={accel}")
+    sc = rtc.Scene(dev, rtc.RTC_SCENE_FLAG_ROBUST)
+    g_sub = sc.add_subdiv(v, fs, fi, displacement=cb)
+    g_tri = sc.add_triangles(gv, gt)
+    sc.set_levels(L, Cl)
+    sc.commit()
+    st = sc.stats()
+    orc_s = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
+    orc_t = po.TriangleScene(gv, gt, 0, np.full(2, g_tri, np.uint32), np.arange(2, dtype=np.uint32))
+    org, d = random_rays_np(200_000, np.array([-4, -3, -4], np.float32), np.array([4, 4, 4], np.float32), 77)
+    want = rtc.aligned_rayhits(200_000)
+    fill_rays(want, org, d)
+    got = want.copy()
+    orc_t.intersect1M(want, nthreads=8)
+    orc_s.intersect1M(want, nthreads=8)
+    sc.intersect1M(got)
+    nh = compare_hits(got, want, what=f"displaced cube {accel}")
+    hit_sub = int((got["geomID"] == g_sub).sum())
+    assert hit_sub > 5000 and nh > hit_sub
+    orc_s.free()
+    orc_t.free()
+    sc.release()
+    dev.release()
+
+
+def test_subdiv_modes_and_errors(rtc):
+    v, fs, fi = _cube()
+    # unknown accel name -> INVALID_ARGUMENT at commit (scene.cpp:511)
+    dev = rtc.Device("subdiv_accel=bvh4.nonsense")
+    sc = rtc.Scene(dev)
+    sc.add_subdiv(v, fs, fi)
+    sc.lib.rtcCommitScene(sc.handle)
+    assert dev.error() == rtc.RTC_ERROR_INVALID_ARGUMENT
+    sc.release()
+    dev.release()
+    # compression level above the subdivision level
+    dev = rtc.Device("subdiv_accel=bvh4.compressed.leaf")
+    sc = rtc.Scene(dev)
+    sc.add_subdiv(v, fs, fi)
+    sc.set_levels(2, 3)
+    sc.lib.rtcCommitScene(sc.handle)
+    assert dev.error() == rtc.RTC_ERROR_INVALID_ARGUMENT
+    sc.release()
+    dev.release()
