@@ -35,6 +35,10 @@ void orc_scene_free(orc_scene* s);
  * embree-compressed_amd/csrc/accel.h).  mode 2: eager grid cells (GridCell, stride 160); mode 3/4/5: fork cBVH blobs
  * (box / leaf / grid) of `stride` bytes with `levels` = compression level C.  The oracle builds its own BVH over them. */
 orc_scene* orc_scene_new_subdiv(const void* blobs, size_t stride, size_t count, int mode, unsigned levels);
+/* Same, but traversing the product's own outer BVH8 (rtcamdGetAccelData kind 0 + rtcamdGetAccelRoot): required for the
+ * order-dependent fork modes box / leaf, see subdiv_oracle.inc. */
+orc_scene* orc_scene_new_subdiv_qbvh(const void* blobs, size_t stride, size_t count, int mode, unsigned levels, const void* qnodes,
+                                     size_t nqnodes, uint32_t rootRef);
 
 /* rayhit: embree3 RTCRayHit layout (80 bytes); ray: RTCRay layout (48 bytes). */
 void orc_intersect1(const orc_scene* s, void* rayhit, uint32_t instID);

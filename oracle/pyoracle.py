@@ -101,13 +101,22 @@ class SubdivScene(TriangleScene):
     """Scene over leaf records exported by the product (rtcamdGetAccelData kind 2).
     mode 2: eager grid cells (stride 160); 3/4/5: fork cBVH blobs box/leaf/grid."""
 
-    def __init__(self, blobs, stride, mode, levels=3):
+    def __init__(self, blobs, stride, mode, levels=3, qnodes=None, root=None):
+        """qnodes/root given: traverse the product's outer BVH8 (same visiting order as the device kernels)."""
         self.L = lib()
         self.L.orc_scene_new_subdiv.restype = C.c_void_p
         self.L.orc_scene_new_subdiv.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint]
+        self.L.orc_scene_new_subdiv_qbvh.restype = C.c_void_p
+        self.L.orc_scene_new_subdiv_qbvh.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_uint, C.c_void_p, C.c_size_t, C.c_uint32]
         self.blobs = np.ascontiguousarray(blobs, dtype=np.uint8)
         assert self.blobs.size % stride == 0
-        self.handle = self.L.orc_scene_new_subdiv(self.blobs.ctypes.data, stride, self.blobs.size // stride, mode, levels)
+        if qnodes is None:
+            self.handle = self.L.orc_scene_new_subdiv(self.blobs.ctypes.data, stride, self.blobs.size // stride, mode, levels)
+        else:
+            self.q = np.ascontiguousarray(qnodes, dtype=np.uint8)
+            assert self.q.size % 96 == 0
+            self.handle = self.L.orc_scene_new_subdiv_qbvh(self.blobs.ctypes.data, stride, self.blobs.size // stride, mode, levels,
+                                                           self.q.ctypes.data, self.q.size // 96, root)
 
 
 def make_random_rays(m, lo, hi, seed=0, double_eval=False, dtype=None):

@@ -34,7 +34,11 @@ def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
     verts, fs, fi = bomberman
     dev, sc = _build(rtc, accel, verts, fs, fi, L, Cl)
     st = sc.stats()
-    orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
+    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+        # order-dependent modes: the oracle must reach the blobs in the same order -> it walks the product's outer BVH8
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
+    else:
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
     lo, hi = verts.min(0), verts.max(0)
     want = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
     got = want.copy()
@@ -52,6 +56,12 @@ def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
         occ[f] = src[f]
     wocc = occ.copy()
     sc.occluded1M(occ)
+    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+        # the any-hit stub does not depend on visiting order: check it against the oracle's own full-precision tree
+        # (the product tests the blob's exact bounds, like the reference's BVH4 leaf boxes; its quantized BVH8 boxes
+        # are only a conservative pre-filter)
+        orc.free()
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
     orc.occluded1M(wocc, nthreads=8)
     if accel == "default":
         assert np.array_equal(occ["tfar"], wocc["tfar"])
@@ -115,7 +125,7 @@ def test_displaced_cube_with_ground_plane(rtc, po, accel):
     sc.set_levels(L, Cl)
     sc.commit()
     st = sc.stats()
-    orc_s = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
+    orc_s = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
     orc_t = po.TriangleScene(gv, gt, 0, np.full(2, g_tri, np.uint32), np.arange(2, dtype=np.uint32))
     org, d = random_rays_np(200_000, np.array([-4, -3, -4], np.float32), np.array([4, 4, 4], np.float32), 77)
     want = rtc.aligned_rayhits(200_000)
