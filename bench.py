@@ -3,18 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W            (N=1 directly; N>1 under torch.distributed.run)
 
-One "step" = one rtcIntersect1M call over one batch of `--rays` device-resident RTCRayHit records (default
-1 M, BASELINE.json configs[1]: random incoherent rays vs the BVH8 of the bomberman triangles).  Every step
-traces a DIFFERENT, freshly generated batch (rays are modified in place by a trace, so re-tracing a batch
-would shrink the work).  Rank r owns its own batches (weak scaling, no data-path collective: SURVEY.md 8e);
-the BVH is replicated per GPU.  Timing: barrier + synchronize on both sides of exactly K steps, MAX over
-ranks; `value` = all rays of all ranks / that time.
+Workload (default `cbvh.leaf`): the scene BASELINE.json's metric is quoted on — bomberman as a Catmull-Clark
+subdivision surface at the reference's bomberman.ecs settings (subdivision level 6, compression level 3,
+`--compress.leaf` = subdiv_accel=bvh4.compressed.leaf: 46 528 cBVH blobs under a quantized BVH8) — traced with
+1 M random incoherent rays per step (the viewer's makeRandomRay generator, drand48 LCG).  `--workload tri`
+selects BASELINE configs[1] (same rays vs the BVH8 of bomberman's 1454 fan triangles), `eager` the default
+GridSOA-style subdiv accel, `cbvh.box` / `cbvh.grid` the other fork modes.  The JSON line of the default run also
+carries the tri and eager rates under config.other_workloads (short runs of the same loop).
+
+One "step" = one rtcIntersect1M call over one batch of device-resident RTCRayHit records.  Every step traces a
+DIFFERENT, freshly generated batch (a trace modifies rays in place, so re-tracing a batch would shrink the work).
+Rank r owns its own batches (weak scaling, no data-path collective: SURVEY.md 8e); the accel is replicated per
+GPU.  Timing: barrier + synchronize on both sides of exactly K steps, MAX over ranks; `value` = all rays of all
+ranks / that time.
 
 The JSON line also carries
   roofline      algorithmic bytes per launch / mean kernel time (HIP events on the launch stream) vs 8 TB/s
   cpu_baseline  the oracle (a scalar C port of the reference's AVX2 path) on the host cores, bounded sample
 """
 import argparse
+import glob
 import importlib
 import json
 import os
@@ -29,6 +37,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec peak
 IO_BYTES_PER_RAY = 84  # 48 B RTCRay read + 36 B (tfar, Ng, u, v, primID, geomID, instID) written
 
+# name -> (device config, geometry kind, oracle mode, dominant-kernel tag in rocprof output, description)
+WORKLOADS = {
+    "cbvh.leaf": ("subdiv_accel=bvh4.compressed.leaf", "subdiv", 4, "CbvhLeaf<1, 3>",
+                  "bomberman.ecs: Catmull-Clark subdiv L6, cBVH C3 pizza-box leaves (bvh4.compressed.leaf), 46528 blobs"),
+    "cbvh.box": ("subdiv_accel=bvh4.compressed.box", "subdiv", 3, "CbvhLeaf<0, 3>", "bomberman subdiv L6/C3, cBVH voxel leaves"),
+    "cbvh.grid": ("subdiv_accel=bvh4.compressed.grid", "subdiv", 5, "CbvhLeaf<2, 3>", "bomberman subdiv L6/C3, cBVH + float vertex grid"),
+    "eager": ("subdiv_accel=default", "subdiv", 2, "GridCellLeaf", "bomberman subdiv L6, eager 3x3-vertex grid cells (GridSOA semantics)"),
+    "tri": ("tri_accel=bvh8.triangle4v", "tri", 0, "TriLeaf<true>", "configs[1]: bomberman.obj as 1454 fan triangles, BVH8 + Triangle4v/Pluecker"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -36,22 +54,23 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1_000_000, help="rays per step per GPU")
-    ap.add_argument("--accel", default="bvh8.triangle4v", help="tri_accel: bvh8.triangle4v (robust/Pluecker) or bvh8.triangle4")
+    ap.add_argument("--workload", default="cbvh.leaf", choices=list(WORKLOADS))
+    ap.add_argument("--levels", default="6,3", help="subdivision level, compression level")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-others", action="store_true", help="skip the short tri / eager side runs")
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_tag):
+def pmc_traffic(kernel_tag, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
-    (profiles/rNN_*_pmc.json, produced by tools/summarize_prof.py; FETCH_SIZE already doubled per the gfx950
+    (profiles/rNN_<workload>_pmc.json by tools/summarize_prof.py; FETCH_SIZE already doubled per the gfx950
     correction).  bench.py cannot collect PMC counters itself; None when no summary is committed."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload.replace('.', '_')}_pmc.json")))
     for path in reversed(files):
         try:
             d = json.load(open(path))
-            rd = [v["read_bytes"] for k, v in d.get("FETCH_SIZE", {}).items() if kernel_tag in k]
-            wr = [v["write_bytes"] for k, v in d.get("WRITE_SIZE", {}).items() if kernel_tag in k]
+            rd = [v["read_bytes"] for k, v in d.get("FETCH_SIZE", {}).items() if kernel_tag in k and "false, false, true>" in k]
+            wr = [v["write_bytes"] for k, v in d.get("WRITE_SIZE", {}).items() if kernel_tag in k and "false, false, true>" in k]
             if rd and wr:
                 return rd[0] + wr[0], os.path.relpath(path, ROOT)
         except (OSError, ValueError, KeyError):
@@ -59,7 +78,21 @@ def pmc_traffic(kernel_tag):
     return None, None
 
 
-def cpu_baseline(verts, tris, lo, hi, m, budget_s, mode):
+def build_scene(rtc, local_rank, workload, mesh, levels):
+    cfg, kind, _, _, _ = WORKLOADS[workload]
+    dev = rtc.Device(f"gpu={local_rank},{cfg}")
+    sc = rtc.Scene(dev)
+    verts, fs, fi = mesh
+    if kind == "tri":
+        sc.add_triangles(verts, rtc.fan_triangulate(fs, fi))
+    else:
+        sc.add_subdiv(verts, fs, fi)
+        sc.set_levels(*levels)
+    sc.commit()
+    return dev, sc
+
+
+def cpu_baseline(sc, rtc, workload, mesh, levels, lo, hi, m, budget_s):
     """Oracle timed on the host cores (kind "port"): the ONLY place bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
@@ -67,7 +100,14 @@ def cpu_baseline(verts, tris, lo, hi, m, budget_s, mode):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    orc = po.TriangleScene(verts, tris, mode)
+    _, kind, mode, _, _ = WORKLOADS[workload]
+    if kind == "tri":
+        orc = po.TriangleScene(mesh[0], rtc.fan_triangulate(mesh[1], mesh[2]), mode)
+        what = "oracle BVH8/Triangle4v restatement"
+    else:
+        st = sc.stats()
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], mode, levels[1], qnodes=sc.accel_data(0), root=sc.accel_root())
+        what = "oracle restatement of CompressedBVHIntersector1 / GridSOAIntersector1 over the same leaf records"
     src = po.make_random_rays(m, lo, hi, seed=12345)
     total, spent, reps = 0, 0.0, 0
     while spent < budget_s and reps < 4096:
@@ -79,53 +119,10 @@ def cpu_baseline(verts, tris, lo, hi, m, budget_s, mode):
         reps += 1
     orc.free()
     return {"value": total / spent / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {m} rays of the same generator (seed 12345), oracle/liboracle.so, {cores} pthreads, blocks of 1024"}
+            "sample": f"{reps} x {m} rays of the same generator (seed 12345), {what} (oracle/liboracle.so), {cores} pthreads, blocks of 1024"}
 
 
-def main():
-    args = parse()
-    import torch
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    pkg = importlib.import_module("embree-compressed_amd")
-    rtc = pkg.rtc
-    raygen = importlib.import_module("embree-compressed_amd.raygen")
-
-    d = np.load(os.path.join(ROOT, "assets", "bomberman.mesh.npz"))
-    verts = d["verts"]
-    tris = rtc.fan_triangulate(d["face_sizes"], d["face_index"])
-    lo, hi = verts.min(0), verts.max(0)
-
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    dev = rtc.Device(f"gpu={local_rank},tri_accel={args.accel}")
-    dev.set_stream(stream.cuda_stream)
-    sc = rtc.Scene(dev)
-    sc.add_triangles(verts, tris)
-    sc.commit()
-    st = sc.stats()
-
-    m, K, W = args.rays, args.steps, args.warmup
-    # distinct batches per step and per rank, generated on the host, resident in HBM before timing starts
-    bufs = []
-    for s in range(K + W + 1):
-        host = raygen.make_random_rays(m, lo, hi, seed=rank * 100003 + s)
-        bufs.append(torch.from_numpy(host).to("cuda", non_blocking=False))
-    torch.cuda.synchronize()
-
-    # work counters on the extra batch -> algorithmic bytes per ray (implementation's own visits x record sizes)
-    cnt = sc.intersect1M_counted(bufs[K + W])
-    n_node = cnt["nodeVisits"] / max(cnt["rays"], 1)
-    n_prim = cnt["primTests"] / max(cnt["rays"], 1)
-    bytes_per_ray = IO_BYTES_PER_RAY + n_node * st["nodeBytes"] + n_prim * st["primBytes"]
-
+def run_loop(torch, dist, sc, dev, stream, bufs, K, W, world):
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -144,49 +141,101 @@ def main():
     t1 = time.perf_counter()
     barrier()
     dev.check("timed region")
-    elapsed = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / K  # HIP events on the launch stream; one kernel per step
+    return t1 - t0, ev0.elapsed_time(ev1) / K  # host-clock region, HIP-event ms per launch on the launch stream
 
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    hits = int((bufs[W].view(torch.int32)[:, 18] != -1).sum().item())
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("embree-compressed_amd")
+    rtc = pkg.rtc
+    raygen = importlib.import_module("embree-compressed_amd.raygen")
+    D = importlib.import_module("embree-compressed_amd.dist")
+
+    d = np.load(os.path.join(ROOT, "assets", "bomberman.mesh.npz"))
+    mesh = (d["verts"], d["face_sizes"], d["face_index"])
+    lo, hi = mesh[0].min(0), mesh[0].max(0)  # bbox of the control vertices, like prepareRandomRays (viewer_device.cpp:394-429)
+    levels = tuple(int(x) for x in args.levels.split(","))
+
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    m, K, W = args.rays, args.steps, args.warmup
+
+    def measure(workload, K, W):
+        dev, sc = build_scene(rtc, local_rank, workload, mesh, levels)
+        dev.set_stream(stream.cuda_stream)
+        # distinct batches per step and per rank, generated on the host, resident in HBM before timing starts
+        bufs = [torch.from_numpy(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))).to("cuda") for s in range(K + W + 1)]
+        torch.cuda.synchronize()
+        cnt = sc.intersect1M_counted(bufs[K + W])  # extra batch: work counters -> algorithmic bytes per ray
+        elapsed, kernel_ms = run_loop(torch, dist, sc, dev, stream, bufs, K, W, world)
+        hits = int((bufs[W].view(torch.int32)[:, 18] != -1).sum().item())
+        return dev, sc, cnt, elapsed, kernel_ms, hits
+
+    dev, sc, cnt, elapsed, kernel_ms, hits = measure(args.workload, K, W)
+    st = sc.stats()
+    rate, worst = D.whole_job_rate(m * K, elapsed, world, device="cuda")
+    n_node = cnt["nodeVisits"] / max(cnt["rays"], 1)
+    n_prim = cnt["primTests"] / max(cnt["rays"], 1)
+    n_inner = cnt["innerVisits"] / max(cnt["rays"], 1)
+    # implementation's own visits x record sizes; a subdiv leaf visit is priced at its whole record
+    bytes_per_ray = IO_BYTES_PER_RAY + n_node * st["nodeBytes"] + n_prim * st["primBytes"]
 
     if rank == 0:
-        total_rays = m * K * world
+        _, _, _, tag, desc = WORKLOADS[args.workload]
         achieved = bytes_per_ray * m / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None)
-        if m == 1_000_000:  # the committed PMC passes were taken on this exact workload
-            tag = "trace_tri_kernel<true, false, false, true>" if args.accel.endswith("4v") else "trace_tri_kernel<false, false, false, true>"
-            traffic, traffic_src = pmc_traffic(tag)
+        if m == 1_000_000 and levels == (6, 3):  # the committed PMC passes were taken on this exact workload
+            traffic, traffic_src = pmc_traffic(tag, args.workload)
         out = {
-            "metric": "Mrays/s (incoherent) on bomberman, device-resident ray batches",
-            "value": total_rays / elapsed / 1e6,
+            "metric": "Mrays/s (incoherent) on bomberman displaced-subdiv scene, device-resident ray batches",
+            "value": rate / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": elapsed / K * 1e3,
+            "ms_per_step": worst / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 1M random incoherent rays (drand48 LCG, bbox-uniform endpoints) vs quantized BVH8 of bomberman.obj fan triangles (1454), rtcIntersect1M on device-resident RTCRayHit[80B]",
-                       "rays_per_step_per_gpu": m, "accel": args.accel, "bvh_nodes": st["nodeCount"], "bvh_bytes": st["totalBytes"],
-                       "hits_first_timed_batch": hits, "sharding": f"replicated BVH, {world} independent ray shards, no collective"},
+            "config": {"workload": f"{args.workload}: {desc}; {m} random incoherent rays per step (drand48 LCG, bbox-uniform endpoints), "
+                                   f"rtcIntersect1M on device-resident RTCRayHit[80B]",
+                       "rays_per_step_per_gpu": m, "accel_kind": st["accelKind"], "bvh_nodes": st["nodeCount"], "leaf_records": st["primCount"],
+                       "leaf_record_bytes": st["primBytes"], "accel_bytes": st["totalBytes"], "hits_first_timed_batch": hits,
+                       "sharding": f"replicated accel, {world} independent ray shards, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms,
-                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "prims_per_ray": n_prim,
-                         "node_bytes": st["nodeBytes"], "prim_bytes": st["primBytes"]},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "kernel": tag,
+                         "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "leaf_visits_per_ray": n_prim,
+                         "inner_steps_per_ray": n_inner, "node_bytes": st["nodeBytes"], "leaf_bytes": st["primBytes"]},
         }
-        if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(verts, tris, lo, hi, m, args.cpu_seconds, 0 if args.accel.endswith("4v") else 1)
-        print(json.dumps(out), flush=True)
-
+    if world == 1 and args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(sc, rtc, args.workload, mesh, levels, lo, hi, m, args.cpu_seconds)
     sc.release()
     dev.release()
+
+    if world == 1 and not args.no_others and args.workload == "cbvh.leaf":
+        others = {}
+        for w2 in ("tri", "eager"):
+            d2, s2, c2, e2, k2, h2 = measure(w2, 5, 2)
+            others[w2] = {"Mrays_per_s": m * 5 / e2 / 1e6, "kernel_ms": k2, "hits": h2, "steps": 5}
+            s2.release()
+            d2.release()
+        out["config"]["other_workloads"] = others
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,4 +1,5 @@
 // Device: config parsing, error funnel, HIP device / stream / staging management.
+#include <algorithm>
 #include <cstdlib>
 #include <pthread.h>
 
@@ -47,6 +48,9 @@ void Device::parse(const std::string& cfg)
 Device::Device(const char* cfg)
 {
   if (const char* env = getenv("RTAMD_GPU")) gpu = atoi(env);
+  if (const char* env = getenv("RTAMD_CHUNK")) tuneChunk = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_LEAF_BATCH")) tuneLeafBatch = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_BLOCKS_PER_CU")) tuneBlocksPerCU = (uint32_t)std::max(0, atoi(env));
   if (cfg) parse(cfg);
   if (gpu == -1) {
     // "gpu=none": host-only object model (build + inspect accels); every trace call raises
@@ -64,6 +68,7 @@ Device::Device(const char* cfg)
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   ownsStream = true;
   HIP_CHECK(hipMalloc(&countersDev, sizeof(TraceCounters)));
+  HIP_CHECK(hipMalloc(&queuesDev, 64 * 32 * 4)); // TRACE_QUEUES heads, one 128-byte line each (TRACE_QUEUE_STRIDE)
   if (verbose >= 1)
     fprintf(stderr, "embree3-amd: device %d (%s, %d CUs), tri_accel=%s subdiv_accel=%s\n", gpu, prop.name, numCUs,
             tri_accel.c_str(), subdiv_accel.c_str());
@@ -81,6 +86,7 @@ Device::~Device()
   if (stageDev) hipFree(stageDev);
   if (spillDev) hipFree(spillDev);
   if (countersDev) hipFree(countersDev);
+  if (queuesDev) hipFree(queuesDev);
 }
 
 void Device::useDevice() const

@@ -50,7 +50,9 @@ struct Device : RefCounted
   void* spillDev = nullptr;
   size_t spillBytes = 0;
   void* countersDev = nullptr;
+  void* queuesDev = nullptr; // 8 x u32 work-queue heads of the persistent kernels
   int numCUs = 256;
+  uint32_t tuneChunk = 128, tuneLeafBatch = 20, tuneBlocksPerCU = 0; // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU)
 
   explicit Device(const char* cfg);
   ~Device() override;

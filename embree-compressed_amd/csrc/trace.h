@@ -19,8 +19,15 @@ struct LaunchParams
   uint32_t gridBlocks; // persistent grid size the spill area was sized for
   uint32_t cbvhLevels; // fork: depth C of every cBVH blob of the scene (rtcSetSceneLevels)
   TraceCounters* counters; // non-null selects the instrumented kernel twin
+  uint32_t numCUs;         // compute units of the device (persistent grid sizing)
+  uint32_t rayChunk;       // rays per work-queue grab (tuning knob, env RTAMD_CHUNK)
+  uint32_t leafBatch;      // lanes waiting at a leaf before the leaf phase runs (tuning knob, env RTAMD_LEAF_BATCH)
+  uint32_t blocksPerCU;    // 0 = occupancy-derived (tuning knob, env RTAMD_BLOCKS_PER_CU)
+  uint32_t* queues;        // 8 work-queue heads (one per blockIdx%8 label), zeroed on the stream before the launch
 };
 
+static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)
+static const int TRACE_QUEUE_STRIDE = 32; // u32 words between two work-queue heads (128 B: one L2 line each)
 static const int TRACE_BLOCK = 256;     // 4 wavefronts per workgroup
 static const int TRACE_LDS_STACK = 16;  // stack entries per lane kept in LDS (8 bytes each -> 32 KiB / workgroup)
 

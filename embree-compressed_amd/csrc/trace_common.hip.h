@@ -234,210 +234,5 @@ template <bool VEC> __device__ __forceinline__ void store_hit(char* p, const Ray
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// the traversal skeleton
-// ---------------------------------------------------------------------------------------------------
-template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK])
-{
-  const uint32_t tid = threadIdx.x;
-  const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
-  const uint32_t gstride = gridDim.x * TRACE_BLOCK;
-  uint2* __restrict__ spill = (uint2*)P.spill + (size_t)gthread * P.spillDepth;
-  const QNode8* __restrict__ nodes = P.accel.nodes;
-
-  WorkCounters wc;
-
-  for (uint32_t i = gthread; i < P.count; i += gstride) {
-    char* rp = (char*)P.rays + (size_t)i * P.stride;
-    RayState r;
-    load_ray<VEC>(rp, r);
-    r.hit = false;
-    // stream front-end: rays with tnear > tfar are skipped (bvh_intersector_stream_filters.cpp:156);
-    // occluded: already-occluded rays return early (bvh_intersector1.cpp:132-134)
-    bool active = r.tnear <= r.tfar;
-    if (OCCLUDED) active = active && !(r.tfar < 0.0f);
-    if (P.accel.root == REF_EMPTY) active = false;
-    if (!active) continue;
-    if (COUNT) wc.rays++;
-
-    TravRay<ROBUST> tr;
-    tr.init(r);
-    float travFar = fmaxf(r.tfar, 0.0f); // tray.tfar
-
-    uint32_t sp = 0; // number of stacked entries
-    uint32_t cur = P.accel.root;
-    bool done = false;
-
-    auto push = [&](uint32_t ref, uint32_t dist, uint32_t slot) {
-      if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
-      else {
-        if (slot - TRACE_LDS_STACK < P.spillDepth) spill[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
-        if (COUNT) wc.spills++;
-      }
-    };
-    auto pop = [&](uint32_t slot) -> uint2 {
-      if (slot < (uint32_t)TRACE_LDS_STACK) return ldsStack[slot][tid];
-      return (slot - TRACE_LDS_STACK < P.spillDepth) ? spill[slot - TRACE_LDS_STACK] : make_uint2(REF_EMPTY, 0x7f800000u);
-    };
-
-    while (!done) {
-      // ---- down traversal ------------------------------------------------------------------------
-      bool popNext = false;
-      while (!(cur & REF_LEAF)) {
-        if (COUNT) wc.nodes++;
-        const uint4* np = (const uint4*)(nodes + cur);
-        const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4], n5 = np[5];
-        const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
-        const float sx = __uint_as_float((n0.w & 0xffu) << 23);
-        const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
-        const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
-        // near / far plane bytes per axis: words .x,.y = lower[0..7], .z,.w = upper[0..7]
-        const uint32_t nx0 = tr.negx ? n3.z : n3.x, nx1 = tr.negx ? n3.w : n3.y;
-        const uint32_t fx0 = tr.negx ? n3.x : n3.z, fx1 = tr.negx ? n3.y : n3.w;
-        const uint32_t ny0 = tr.negy ? n4.z : n4.x, ny1 = tr.negy ? n4.w : n4.y;
-        const uint32_t fy0 = tr.negy ? n4.x : n4.z, fy1 = tr.negy ? n4.y : n4.w;
-        const uint32_t nz0 = tr.negz ? n5.z : n5.x, nz1 = tr.negz ? n5.w : n5.y;
-        const uint32_t fz0 = tr.negz ? n5.x : n5.z, fz1 = tr.negz ? n5.y : n5.w;
-        const uint32_t cref[8] = {n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
-
-        uint32_t dist[8];
-        uint32_t mask = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int kk = k & 3;
-          const float npx = madd(q2f(k < 4 ? nx0 : nx1, kk), sx, ox);
-          const float npy = madd(q2f(k < 4 ? ny0 : ny1, kk), sy, oy);
-          const float npz = madd(q2f(k < 4 ? nz0 : nz1, kk), sz, oz);
-          const float fpx = madd(q2f(k < 4 ? fx0 : fx1, kk), sx, ox);
-          const float fpy = madd(q2f(k < 4 ? fy0 : fy1, kk), sy, oy);
-          const float fpz = madd(q2f(k < 4 ? fz0 : fz1, kk), sz, oz);
-          const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
-          const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
-          const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
-          dist[k] = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
-          mask |= h ? (1u << k) : 0u;
-        }
-        if (mask == 0) { popNext = true; break; }
-
-        const int nhit = __popc(mask);
-        if (nhit == 1) {
-          const int k = __ffs(mask) - 1;
-          uint32_t c = cref[0];
-#pragma unroll
-          for (int j = 1; j < 8; j++) c = (k == j) ? cref[j] : c;
-          cur = c;
-          continue;
-        }
-        if (OCCLUDED) {
-          // traverseAnyHit (bvh_traverser1.h:638-666): descend into the highest-index hit child, stack the rest
-          // in ascending index order, no sorting.
-          uint32_t slot = sp;
-          uint32_t last = REF_EMPTY;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            if (mask & (1u << k)) {
-              if (last != REF_EMPTY) { push(last, 0u, slot); slot++; }
-              last = cref[k];
-            }
-          }
-          sp = slot;
-          cur = last;
-          continue;
-        }
-        // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
-        // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80).  rank[k] = #children visited before k.
-        uint32_t rank[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) rank[k] = 0;
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-#pragma unroll
-          for (int b = a + 1; b < 8; b++) {
-            const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u; // tie -> b (higher index) first
-            rank[b] += aFirst;
-            rank[a] += 1u - aFirst;
-          }
-        }
-        // non-hit children carry 0xFFFFFFFF and sort behind every hit child (among themselves irrelevant)
-        const uint32_t base = sp + (uint32_t)nhit - 1u;
-        uint32_t next = REF_EMPTY;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (mask & (1u << k)) {
-            if (rank[k] == 0) next = cref[k];
-            else push(cref[k], dist[k], base - rank[k]);
-          }
-        }
-        sp = base;
-        cur = next;
-      }
-
-      // ---- leaf ------------------------------------------------------------------------------------
-      if (!popNext) {
-        if (COUNT) wc.leaves++;
-        if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
-          r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
-          r.hit = true;
-          break;
-        }
-        travFar = r.tfar; // tray.tfar = ray.tfar (bvh_intersector1.cpp:117)
-      }
-
-      // ---- pop ---------------------------------------------------------------------------------------
-      for (;;) {
-        if (sp == 0) { done = true; break; }
-        sp--;
-        const uint2 e = pop(sp);
-        if (e.x == REF_EMPTY) continue;                           // entry lost to an exhausted spill area
-        if (!OCCLUDED && __uint_as_float(e.y) > r.tfar) continue; // bvh_intersector1.cpp:86
-        cur = e.x;
-        break;
-      }
-    }
-
-    if (r.hit) {
-      if (COUNT) wc.hits++;
-      if (OCCLUDED) ((float*)rp)[8] = r.tfar;
-      else store_hit<VEC>(rp, r, P.instID);
-    }
-  }
-
-  if (COUNT) {
-    TraceCounters* c = P.counters;
-    atomicAdd(&c->rays, wc.rays);
-    atomicAdd(&c->nodeVisits, wc.nodes);
-    atomicAdd(&c->leafVisits, wc.leaves);
-    atomicAdd(&c->primTests, wc.prims);
-    atomicAdd(&c->innerVisits, wc.inner);
-    atomicAdd(&c->hits, wc.hits);
-    atomicAdd(&c->stackSpills, wc.spills);
-  }
-}
-
-template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(LaunchParams P)
-{
-  __shared__ uint2 ldsStack[TRACE_LDS_STACK][TRACE_BLOCK];
-  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack);
-}
-
-template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT>
-inline hipError_t launch_vec(const LaunchParams& p, hipStream_t stream)
-{
-  const bool vec = (p.stride % 16 == 0) && (((uintptr_t)p.rays) % 16 == 0);
-  if (vec) hipLaunchKernelGGL((trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, true>), dim3(p.gridBlocks), dim3(TRACE_BLOCK), 0, stream, p);
-  else hipLaunchKernelGGL((trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, false>), dim3(p.gridBlocks), dim3(TRACE_BLOCK), 0, stream, p);
-  return hipGetLastError();
-}
-
-template <typename Leaf, bool ROBUST>
-inline hipError_t launch_leaf(const LaunchParams& p, hipStream_t stream)
-{
-  const bool cnt = p.counters != nullptr;
-  if (p.occluded) return cnt ? launch_vec<Leaf, ROBUST, true, true>(p, stream) : launch_vec<Leaf, ROBUST, true, false>(p, stream);
-  return cnt ? launch_vec<Leaf, ROBUST, false, true>(p, stream) : launch_vec<Leaf, ROBUST, false, false>(p, stream);
-}
-
 } // namespace dev
 } // namespace rtamd

@@ -1,0 +1,311 @@
+// The traversal kernel skeleton: persistent wavefronts with dynamic ray fetch and per-lane LDS stacks.
+//
+// MI355X design (not a port of the reference's per-ray CPU loop):
+//  * Persistent grid (5 workgroups of 4 waves per CU).  Rays are pulled from 8 work queues (one per blockIdx%8 label,
+//    i.e. per XCD under round-robin placement; the label is used for speed only) in chunks of 128, so that the
+//    atomic traffic stays far below what one counter word sustains and the batch is balanced dynamically: random
+//    rays differ by more than 10x in traversal cost and a static assignment leaves most SIMDs idle in the tail.
+//  * A lane whose ray has finished is refilled from the wave's chunk (ballot + mbcnt rank), so finished rays do
+//    not park lanes ("wavefront ballot for active-ray compaction").
+//  * if-if traversal step: every iteration each lane handles ONE event: an inner node, a leaf, or a pop.  Leaves
+//    are expensive and rare, so lanes that reached a leaf wait until LEAF_BATCH lanes want one (or no lane can do
+//    node work): the leaf code then runs with many lanes active instead of a handful.
+//  * Per-lane traversal stack in LDS, entry-major (stack[entry][lane]: bank = lane, never a conflict, whatever
+//    the depth mix), with an HBM overflow area for pathological depths.
+// Per-ray semantics are untouched by any of this: each lane performs exactly the reference's depth-first sequence
+// for its ray (kernels/bvh/bvh_intersector1.cpp:40-126 closest hit, :128-209 any hit; child order
+// kernels/bvh/bvh_traverser1.h:549-666 with the tie rules of kernels/common/stack_item.h:39-80).
+//
+// A kernel is this skeleton instantiated with a Leaf policy:
+//   struct Leaf { template<bool OCCLUDED,bool COUNT> static __device__ bool intersect(const LaunchParams&, uint32_t ref, RayState&, WorkCounters&); }
+// returning true when an any-hit query is finished (ray occluded).
+#pragma once
+#include "trace_common.hip.h"
+
+namespace rtamd {
+namespace dev {
+
+static constexpr uint32_t RAY_CHUNK = 128;  // default rays a wave takes from a queue per atomic (LaunchParams::rayChunk)
+static constexpr uint32_t QUEUE_STRIDE = TRACE_QUEUE_STRIDE; // queue heads live in separate 128-byte lines
+static constexpr int LEAF_BATCH = 20;       // default lanes that must wait at a leaf before the leaf code runs (LaunchParams::leafBatch)
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) // number of set bits of `mask` below this lane
+{
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
+__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK])
+{
+  const uint32_t tid = threadIdx.x;
+  const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
+  uint2* __restrict__ spill = (uint2*)P.spill + (size_t)gthread * P.spillDepth;
+  const QNode8* __restrict__ nodes = P.accel.nodes;
+  uint32_t* __restrict__ queues = P.queues;
+
+  // TRACE_QUEUES work queues; queue q owns the contiguous rays [q*perQ, (q+1)*perQ).  One RMW on a queue head costs
+  // ~70 ns serialized per address on MI355X (measured: 8 queues x 128-ray chunks made the grabs alone cost ~60 us per
+  // 1 M rays), so the heads are spread over 64 addresses in separate 128-byte lines; a wave starts at its home queue
+  // and, when that is drained, finds the next non-empty queue with ONE vector load of all heads.
+  const uint32_t perQ = (P.count + (uint32_t)TRACE_QUEUES - 1u) / (uint32_t)TRACE_QUEUES;
+  const uint32_t laneId = lane_rank(~0ull);
+  uint32_t qCur = (blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6)) & (uint32_t)(TRACE_QUEUES - 1); // wave-uniform
+  uint32_t poolNext = 0, poolEnd = 0; // wave-uniform: rays [poolNext, poolEnd) belong to this wave
+  bool exhausted = P.accel.root == REF_EMPTY;
+
+  WorkCounters wc;
+  RayState r;
+  TravRay<ROBUST> tr;
+  float travFar = 0.f;
+  uint32_t sp = 0, cur = REF_EMPTY, rayIdx = 0;
+  bool active = false, needPop = false;
+  r.hit = false;
+
+  auto push = [&](uint32_t ref, uint32_t dist, uint32_t slot) {
+    if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
+    else {
+      if (slot - TRACE_LDS_STACK < P.spillDepth) spill[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
+      if (COUNT) wc.spills++;
+    }
+  };
+  auto pop = [&](uint32_t slot) -> uint2 {
+    if (slot < (uint32_t)TRACE_LDS_STACK) return ldsStack[slot][tid];
+    return (slot - TRACE_LDS_STACK < P.spillDepth) ? spill[slot - TRACE_LDS_STACK] : make_uint2(REF_EMPTY, 0x7f800000u);
+  };
+
+  for (;;) {
+    // ---- refill idle lanes ---------------------------------------------------------------------------
+    const uint64_t idleMask = __ballot(!active);
+    if (idleMask != 0ull && !exhausted) {
+      if (poolNext == poolEnd) { // take a new chunk (one lane does the atomic, the result is wave-uniform)
+        for (;;) {
+          const uint32_t qLo = min(qCur * perQ, P.count);
+          const uint32_t qHi = min(qLo + perQ, P.count);
+          uint32_t base = 0;
+          if (laneId == 0u) base = atomicAdd(&queues[qCur * QUEUE_STRIDE], P.rayChunk);
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (base < qHi - qLo) {
+            poolNext = qLo + base;
+            poolEnd = min(poolNext + P.rayChunk, qHi);
+            break;
+          }
+          // drained: lane l reads head l (heads only grow, so a stale value can only under-report "drained"), the
+          // ballot marks the queues that still have rays, take the next one cyclically after qCur
+          const uint32_t myLo = min(laneId * perQ, P.count), myHi = min(myLo + perQ, P.count);
+          const uint32_t head = __hip_atomic_load(&queues[laneId * QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint64_t live = __ballot(laneId < (uint32_t)TRACE_QUEUES && head < myHi - myLo);
+          if (live == 0ull) { exhausted = true; break; }
+          const uint64_t rot = (live >> qCur) | (qCur ? (live << (64u - qCur)) : 0ull); // bit k = queue (qCur+k)&63
+          qCur = (qCur + (uint32_t)__builtin_ctzll(rot)) & (uint32_t)(TRACE_QUEUES - 1);
+        }
+      }
+      if (poolNext != poolEnd) {
+        const uint32_t mine = poolNext + lane_rank(idleMask);
+        if (!active && mine < poolEnd) {
+          rayIdx = mine;
+          const char* rp = (const char*)P.rays + (size_t)rayIdx * P.stride;
+          load_ray<VEC>(rp, r);
+          r.hit = false;
+          // stream front-end: rays with tnear > tfar are skipped (bvh_intersector_stream_filters.cpp:156);
+          // occluded: already-occluded rays return early (bvh_intersector1.cpp:132-134)
+          bool ok = r.tnear <= r.tfar;
+          if (OCCLUDED) ok = ok && !(r.tfar < 0.0f);
+          if (ok) {
+            if (COUNT) wc.rays++;
+            tr.init(r);
+            travFar = fmaxf(r.tfar, 0.0f); // tray.tfar
+            sp = 0;
+            cur = P.accel.root;
+            needPop = false;
+            active = true;
+          }
+        }
+        poolNext = min(poolNext + (uint32_t)__popcll(idleMask), poolEnd);
+      }
+    }
+    if (__ballot(active) == 0ull) {
+      if (exhausted) break;
+      continue;
+    }
+
+    // ---- inner node step ---------------------------------------------------------------------------------
+    const bool atLeaf = active && !needPop && (cur & REF_LEAF);
+    const bool atNode = active && !needPop && !(cur & REF_LEAF);
+    if (atNode) {
+      if (COUNT) wc.nodes++;
+      const uint4* np = (const uint4*)(nodes + cur);
+      const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4], n5 = np[5];
+      const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+      const float sx = __uint_as_float((n0.w & 0xffu) << 23);
+      const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
+      const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+      // near / far plane bytes per axis: words .x,.y = lower[0..7], .z,.w = upper[0..7]
+      const uint32_t nx0 = tr.negx ? n3.z : n3.x, nx1 = tr.negx ? n3.w : n3.y;
+      const uint32_t fx0 = tr.negx ? n3.x : n3.z, fx1 = tr.negx ? n3.y : n3.w;
+      const uint32_t ny0 = tr.negy ? n4.z : n4.x, ny1 = tr.negy ? n4.w : n4.y;
+      const uint32_t fy0 = tr.negy ? n4.x : n4.z, fy1 = tr.negy ? n4.y : n4.w;
+      const uint32_t nz0 = tr.negz ? n5.z : n5.x, nz1 = tr.negz ? n5.w : n5.y;
+      const uint32_t fz0 = tr.negz ? n5.x : n5.z, fz1 = tr.negz ? n5.y : n5.w;
+      const uint32_t cref[8] = {n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+
+      uint32_t dist[8];
+      uint32_t mask = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int kk = k & 3;
+        const float npx = madd(q2f(k < 4 ? nx0 : nx1, kk), sx, ox);
+        const float npy = madd(q2f(k < 4 ? ny0 : ny1, kk), sy, oy);
+        const float npz = madd(q2f(k < 4 ? nz0 : nz1, kk), sz, oz);
+        const float fpx = madd(q2f(k < 4 ? fx0 : fx1, kk), sx, ox);
+        const float fpy = madd(q2f(k < 4 ? fy0 : fy1, kk), sy, oy);
+        const float fpz = madd(q2f(k < 4 ? fz0 : fz1, kk), sz, oz);
+        const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
+        const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
+        const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
+        dist[k] = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+        mask |= h ? (1u << k) : 0u;
+      }
+      const int nhit = __popc(mask);
+      if (nhit == 0) needPop = true;
+      else if (nhit == 1) {
+        const int k = __ffs(mask) - 1;
+        uint32_t c = cref[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) c = (k == j) ? cref[j] : c;
+        cur = c;
+      } else if (OCCLUDED) {
+        // traverseAnyHit (bvh_traverser1.h:638-666): descend into the highest-index hit child, stack the rest
+        // in ascending index order, no sorting.
+        uint32_t slot = sp;
+        uint32_t last = REF_EMPTY;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (mask & (1u << k)) {
+            if (last != REF_EMPTY) { push(last, 0u, slot); slot++; }
+            last = cref[k];
+          }
+        }
+        sp = slot;
+        cur = last;
+      } else {
+        // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
+        // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80).  rank[k] = #children visited before k.
+        uint32_t rank[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) rank[k] = 0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+#pragma unroll
+          for (int b = a + 1; b < 8; b++) {
+            const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u; // tie -> b (higher index) first
+            rank[b] += aFirst;
+            rank[a] += 1u - aFirst;
+          }
+        }
+        // non-hit children carry 0xFFFFFFFF and sort behind every hit child (among themselves irrelevant)
+        const uint32_t base = sp + (uint32_t)nhit - 1u;
+        uint32_t next = REF_EMPTY;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          if (mask & (1u << k)) {
+            if (rank[k] == 0) next = cref[k];
+            else push(cref[k], dist[k], base - rank[k]);
+          }
+        }
+        sp = base;
+        cur = next;
+      }
+    }
+
+    // ---- leaf step: run only when enough lanes wait at a leaf, or when nobody has node work -------------------
+    const uint64_t leafMask = __ballot(atLeaf);
+    if (leafMask != 0ull) {
+      const bool nodeWork = __ballot(atNode) != 0ull;
+      if (__popcll(leafMask) >= (int)P.leafBatch || !nodeWork) {
+        if (atLeaf) {
+          if (COUNT) wc.leaves++;
+          if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
+            r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
+            r.hit = true;
+            sp = 0;           // any hit found: terminate this ray
+          }
+          travFar = OCCLUDED ? travFar : r.tfar; // tray.tfar = ray.tfar (bvh_intersector1.cpp:117)
+          needPop = true;
+        }
+      }
+    }
+
+    // ---- pop -------------------------------------------------------------------------------------------------------
+    if (active && needPop) {
+      bool finished = false;
+      for (;;) {
+        if (sp == 0) { finished = true; break; }
+        sp--;
+        const uint2 e = pop(sp);
+        if (e.x == REF_EMPTY) continue;                           // entry lost to an exhausted spill area
+        if (!OCCLUDED && __uint_as_float(e.y) > r.tfar) continue; // bvh_intersector1.cpp:86
+        cur = e.x;
+        break;
+      }
+      needPop = false;
+      if (finished) {
+        if (r.hit) {
+          char* rp = (char*)P.rays + (size_t)rayIdx * P.stride;
+          if (COUNT) wc.hits++;
+          if (OCCLUDED) ((float*)rp)[8] = r.tfar;
+          else store_hit<VEC>(rp, r, P.instID);
+        }
+        active = false;
+      }
+    }
+  }
+
+  if (COUNT) {
+    TraceCounters* c = P.counters;
+    atomicAdd(&c->rays, wc.rays);
+    atomicAdd(&c->nodeVisits, wc.nodes);
+    atomicAdd(&c->leafVisits, wc.leaves);
+    atomicAdd(&c->primTests, wc.prims);
+    atomicAdd(&c->innerVisits, wc.inner);
+    atomicAdd(&c->hits, wc.hits);
+    atomicAdd(&c->stackSpills, wc.spills);
+  }
+}
+
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
+__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(LaunchParams P)
+{
+  __shared__ uint2 ldsStack[TRACE_LDS_STACK][TRACE_BLOCK];
+  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack);
+}
+
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT>
+inline hipError_t launch_vec(const LaunchParams& p, hipStream_t stream)
+{
+  const bool vec = (p.stride % 16 == 0) && (((uintptr_t)p.rays) % 16 == 0);
+  // persistent grid = what is resident at once for THIS instantiation (its VGPR budget decides), capped by the
+  // host's bound (which sized the spill area) and by the work available
+  static int occVec = 0, occGen = 0;
+  int& occ = vec ? occVec : occGen;
+  if (occ == 0) {
+    hipError_t e = vec ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, true>, TRACE_BLOCK, 0)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, false>, TRACE_BLOCK, 0);
+    if (e != hipSuccess || occ <= 0) occ = 1;
+  }
+  uint32_t blocks = (p.blocksPerCU ? std::min<uint32_t>(p.blocksPerCU, (uint32_t)occ) : (uint32_t)occ) * p.numCUs;
+  if (blocks > p.gridBlocks) blocks = p.gridBlocks;
+  if (vec) hipLaunchKernelGGL((trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, p);
+  else hipLaunchKernelGGL((trace_kernel<Leaf, ROBUST, OCCLUDED, COUNT, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, stream, p);
+  return hipGetLastError();
+}
+
+template <typename Leaf, bool ROBUST>
+inline hipError_t launch_leaf(const LaunchParams& p, hipStream_t stream)
+{
+  const bool cnt = p.counters != nullptr;
+  if (p.occluded) return cnt ? launch_vec<Leaf, ROBUST, true, true>(p, stream) : launch_vec<Leaf, ROBUST, true, false>(p, stream);
+  return cnt ? launch_vec<Leaf, ROBUST, false, true>(p, stream) : launch_vec<Leaf, ROBUST, false, false>(p, stream);
+}
+
+} // namespace dev
+} // namespace rtamd

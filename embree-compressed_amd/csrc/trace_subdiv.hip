@@ -12,7 +12,7 @@
 // that produced them (compressed.h:544-549,617); the traversal ray's tfar is never tightened (compressed.h:523).
 // Scalar arithmetic of the fork is written without fused operations (the reference leaves contraction to its
 // compiler; this path is "parity unpinned").
-#include "trace_common.hip.h"
+#include "trace_loop.hip.h"
 
 namespace rtamd {
 namespace dev {

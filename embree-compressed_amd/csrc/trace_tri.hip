@@ -3,7 +3,7 @@
 // reference's 4-wide SIMD semantics.
 //   block loop            kernels/geometry/intersector_iterators.h:32-36 (ArrayIntersector1)
 //   epilog / tie rules    kernels/geometry/intersector_epilog.h:226-307 (closest), :388-450 (any hit)
-#include "trace_common.hip.h"
+#include "trace_loop.hip.h"
 
 namespace rtamd {
 namespace dev {
