@@ -52,7 +52,8 @@ struct Device : RefCounted
   void* countersDev = nullptr;
   void* queuesDev = nullptr; // 8 x u32 work-queue heads of the persistent kernels
   int numCUs = 256;
-  uint32_t tuneChunk = 128, tuneLeafBatch = 20, tuneBlocksPerCU = 0; // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU)
+  uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
+  uint32_t tuneChunk = 128, tuneLeafBatch = 24, tuneBlocksPerCU = 0; // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU)
 
   explicit Device(const char* cfg);
   ~Device() override;

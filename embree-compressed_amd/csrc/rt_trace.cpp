@@ -48,6 +48,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   p.rayChunk = dev->tuneChunk;
   p.leafBatch = dev->tuneLeafBatch;
   p.blocksPerCU = dev->tuneBlocksPerCU;
+  p.refillBatch = dev->tuneRefillBatch;
   p.queues = (uint32_t*)dev->queuesDev;
   HIP_CHECK(hipMemsetAsync(dev->queuesDev, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, dev->stream));
   HIP_CHECK(launch_trace(p, dev->stream));

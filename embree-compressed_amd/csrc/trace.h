@@ -23,6 +23,7 @@ struct LaunchParams
   uint32_t rayChunk;       // rays per work-queue grab (tuning knob, env RTAMD_CHUNK)
   uint32_t leafBatch;      // lanes waiting at a leaf before the leaf phase runs (tuning knob, env RTAMD_LEAF_BATCH)
   uint32_t blocksPerCU;    // 0 = occupancy-derived (tuning knob, env RTAMD_BLOCKS_PER_CU)
+  uint32_t refillBatch;    // idle lanes needed before a wave fetches new rays (tuning knob, env RTAMD_REFILL_BATCH)
   uint32_t* queues;        // 8 work-queue heads (one per blockIdx%8 label), zeroed on the stream before the launch
 };
 

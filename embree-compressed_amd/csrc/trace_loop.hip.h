@@ -25,6 +25,13 @@
 namespace rtamd {
 namespace dev {
 
+// Minimum resident waves per SIMD requested from the register allocator (second __launch_bounds__ argument).
+// Measured on MI355X (1 M rays, bomberman L6/C3): asking for 4 or 5 waves makes the subdivision kernels spill
+// 76-168 bytes per lane and costs 12-48 % (cbvh.leaf 5.44 -> 4.81 -> 3.92 Grays/s), so the bound stays at 3
+// (<= 168 VGPRs, no scratch); the triangle kernels need 103 VGPRs and get 4 waves either way.
+#ifndef TRACE_MIN_WAVES_PER_SIMD
+#define TRACE_MIN_WAVES_PER_SIMD 3
+#endif
 static constexpr uint32_t RAY_CHUNK = 128;  // default rays a wave takes from a queue per atomic (LaunchParams::rayChunk)
 static constexpr uint32_t QUEUE_STRIDE = TRACE_QUEUE_STRIDE; // queue heads live in separate 128-byte lines
 static constexpr int LEAF_BATCH = 20;       // default lanes that must wait at a leaf before the leaf code runs (LaunchParams::leafBatch)
@@ -76,7 +83,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   for (;;) {
     // ---- refill idle lanes ---------------------------------------------------------------------------
     const uint64_t idleMask = __ballot(!active);
-    if (idleMask != 0ull && !exhausted) {
+    // refilling a handful of lanes costs as many instructions as refilling all 64: wait until refillBatch lanes are
+    // idle (or until nothing else can run)
+    if (idleMask != 0ull && !exhausted && (__popcll(idleMask) >= (int)P.refillBatch || idleMask == ~0ull)) {
       if (poolNext == poolEnd) { // take a new chunk (one lane does the atomic, the result is wave-uniform)
         for (;;) {
           const uint32_t qLo = min(qCur * perQ, P.count);
@@ -273,7 +282,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__global__ __launch_bounds__(TRACE_BLOCK) void trace_kernel(LaunchParams P)
+__global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES_PER_SIMD) void trace_kernel(LaunchParams P)
 {
   __shared__ uint2 ldsStack[TRACE_LDS_STACK][TRACE_BLOCK];
   trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack);

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libembree3.so")
+LIB_PATH = os.environ.get("RTAMD_LIB", os.path.join(_HERE, "lib", "libembree3.so"))  # RTAMD_LIB: A/B builds of the same library
 
 RTC_INVALID_GEOMETRY_ID = 0xFFFFFFFF
 
