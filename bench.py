@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--levels", default="6,3", help="subdivision level, compression level")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-others", action="store_true", help="skip the short tri / eager side runs")
+    ap.add_argument("--rays-kind", default="random", choices=["random", "primary"],
+                    help="random: the metric's incoherent bbox rays; primary: BASELINE config 4, 1920x1080 camera rays of bomberman.ecs")
     return ap.parse_args()
 
 
@@ -170,12 +172,19 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     m, K, W = args.rays, args.steps, args.warmup
+    primary = None
+    if args.rays_kind == "primary":
+        primary = raygen.make_primary_rays()
+        m = primary.shape[0]
 
     def measure(workload, K, W):
         dev, sc = build_scene(rtc, local_rank, workload, mesh, levels)
         dev.set_stream(stream.cuda_stream)
         # distinct batches per step and per rank, generated on the host, resident in HBM before timing starts
-        bufs = [torch.from_numpy(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))).to("cuda") for s in range(K + W + 1)]
+        if primary is not None:  # the same camera frame every step, but a fresh copy (a trace modifies rays in place)
+            bufs = [torch.from_numpy(primary).to("cuda") for s in range(K + W + 1)]
+        else:
+            bufs = [torch.from_numpy(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))).to("cuda") for s in range(K + W + 1)]
         torch.cuda.synchronize()
         cnt = sc.intersect1M_counted(bufs[K + W])  # extra batch: work counters -> algorithmic bytes per ray
         elapsed, kernel_ms = run_loop(torch, dist, sc, dev, stream, bufs, K, W, world)
@@ -195,7 +204,7 @@ def main():
         _, _, _, tag, desc = WORKLOADS[args.workload]
         achieved = bytes_per_ray * m / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None)
-        if m == 1_000_000 and levels == (6, 3):  # the committed PMC passes were taken on this exact workload
+        if m == 1_000_000 and levels == (6, 3) and primary is None:  # the committed PMC passes were taken on this exact workload
             traffic, traffic_src = pmc_traffic(tag, args.workload)
         out = {
             "metric": "Mrays/s (incoherent) on bomberman displaced-subdiv scene, device-resident ray batches",
@@ -210,8 +219,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {desc}; {m} random incoherent rays per step (drand48 LCG, bbox-uniform endpoints), "
-                                   f"rtcIntersect1M on device-resident RTCRayHit[80B]",
+            "config": {"workload": f"{args.workload}: {desc}; {m} "
+                                   + ("random incoherent rays per step (drand48 LCG, bbox-uniform endpoints), " if primary is None else
+                                      "coherent primary rays per step (config 4: 1920x1080, bomberman.ecs camera, 8x8 tile order), ")
+                                   + "rtcIntersect1M on device-resident RTCRayHit[80B]",
                        "rays_per_step_per_gpu": m, "accel_kind": st["accelKind"], "bvh_nodes": st["nodeCount"], "leaf_records": st["primCount"],
                        "leaf_record_bytes": st["primBytes"], "accel_bytes": st["totalBytes"], "hits_first_timed_batch": hits,
                        "sharding": f"replicated accel, {world} independent ray shards, no collective"},

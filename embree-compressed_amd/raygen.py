@@ -53,6 +53,45 @@ def make_random_rays(m, lo, hi, seed=0):
     return rec.view(np.uint8).reshape(m, RAYHIT_BYTES)
 
 
+def make_primary_rays(width=1920, height=1080, frm=(18.21240425, 20.05745888, 15.46878433), to=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
+                      fov=90.0, tile=8):
+    """Coherent primary rays of BASELINE config 4 (viewer_stream on build/bomberman.ecs): pinhole camera of
+    Camera::getISPCCamera (tutorials/common/tutorial/camera.h:74-88, right-handed lookat), one ray per pixel,
+    dir = normalize(x*vx + y*vy + vz), emitted tile by tile (8x8, row-major tiles, row-major inside a tile) like
+    renderTileStandard (tutorials/viewer_stream/viewer_stream_device.cpp:288-325).  Returns uint8 [W*H, 80]."""
+    f32 = np.float32
+    frm, to, up = (np.asarray(a, dtype=f32) for a in (frm, to, up))
+
+    def norm(a):
+        return (a / np.sqrt(np.dot(a, a), dtype=f32)).astype(f32)
+
+    Z = norm(to - frm)
+    U = norm(np.cross(up, Z).astype(f32))
+    V = norm(np.cross(Z, U).astype(f32))
+    U = -U  # RIGHT_HANDED: local2world.l.vx = -vx
+    fov_scale = f32(1.0) / np.tan(np.deg2rad(f32(0.5) * f32(fov)), dtype=f32)
+    vx, vy = U, -V
+    vz = (f32(-0.5 * width) * U + f32(0.5 * height) * V + f32(0.5 * height) * fov_scale * Z).astype(f32)
+    ys, xs = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
+    # tile order
+    ty, tx = ys // tile, xs // tile
+    order = np.lexsort((xs.ravel(), ys.ravel(), tx.ravel(), ty.ravel()))
+    x = xs.ravel()[order].astype(f32)
+    y = ys.ravel()[order].astype(f32)
+    d = (x[:, None] * vx[None, :] + y[:, None] * vy[None, :] + vz[None, :]).astype(f32)
+    d = (d / np.sqrt((d * d).sum(1, dtype=f32), dtype=f32)[:, None]).astype(f32)
+    m = width * height
+    rec = np.zeros((m, 20), dtype=f32)
+    rec[:, 0:3] = frm[None, :]
+    rec[:, 4:7] = d
+    rec[:, 8] = np.inf
+    w = rec.view(np.uint32)
+    w[:, 9] = 0xFFFFFFFF
+    w[:, 10] = np.arange(m, dtype=np.uint32)
+    w[:, 17:20] = 0xFFFFFFFF
+    return rec.view(np.uint8).reshape(m, RAYHIT_BYTES)
+
+
 def shard_range(total, rank, world):
     """Contiguous ray-index range of `rank`: [rank*total/world, (rank+1)*total/world)."""
     return (rank * total) // world, ((rank + 1) * total) // world

@@ -143,6 +143,29 @@ def test_displaced_cube_with_ground_plane(rtc, po, accel):
     dev.release()
 
 
+@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf"])
+def test_primary_rays_config4(rtc, po, bomberman, accel):
+    """BASELINE config 4: coherent camera rays of build/bomberman.ecs (here 480x270, tile order), almost all of which
+    hit the scene, so leaves dominate the work; same-tree oracle (the fork's leaf mode is order dependent)."""
+    import importlib
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    verts, fs, fi = bomberman
+    dev, sc = _build(rtc, accel, verts, fs, fi, 5, 3)
+    st = sc.stats()
+    orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 3, qnodes=sc.accel_data(0), root=sc.accel_root())
+    raw = rg.make_primary_rays(480, 270)
+    want = rtc.aligned_rayhits(raw.shape[0])
+    want[:] = raw.reshape(-1).view(rtc.RAYHIT_DTYPE)
+    got = want.copy()
+    orc.intersect1M(want, nthreads=8)
+    sc.intersect1M(got)
+    nh = compare_hits(got, want, what=f"primary {accel}")
+    assert nh > 0.7 * raw.shape[0]
+    orc.free()
+    sc.release()
+    dev.release()
+
+
 def test_subdiv_modes_and_errors(rtc):
     v, fs, fi = _cube()
     # unknown accel name -> INVALID_ARGUMENT at commit (scene.cpp:511)
