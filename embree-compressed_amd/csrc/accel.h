@@ -128,6 +128,7 @@ struct AccelDesc
 struct TraceCounters
 {
   unsigned long long rays, nodeVisits, leafVisits, primTests, innerVisits, hits, stackSpills, reserved;
+  unsigned long long cyclesFetch, cyclesNode, cyclesLeaf, cyclesPop, cyclesTotal, iterations, leafPhases, waves;
 };
 
 } // namespace rtamd

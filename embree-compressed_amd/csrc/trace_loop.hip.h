@@ -80,7 +80,19 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     return (slot - TRACE_LDS_STACK < P.spillDepth) ? spill[slot - TRACE_LDS_STACK] : make_uint2(REF_EMPTY, 0x7f800000u);
   };
 
+  // phase stamps of the instrumented twin: s_memtime around the wave-uniform phases (diagnostic only)
+  unsigned long long tFetch = 0, tNode = 0, tLeaf = 0, tPop = 0, nIter = 0, nLeafPhase = 0, tStamp = 0, tBegin = 0;
+  auto stamp = [&](unsigned long long& acc) {
+    if (COUNT) {
+      const unsigned long long now = __builtin_readcyclecounter();
+      acc += now - tStamp;
+      tStamp = now;
+    }
+  };
+  if (COUNT) tBegin = tStamp = __builtin_readcyclecounter();
+
   for (;;) {
+    if (COUNT) nIter++;
     // ---- refill idle lanes ---------------------------------------------------------------------------
     const uint64_t idleMask = __ballot(!active);
     // refilling a handful of lanes costs as many instructions as refilling all 64: wait until refillBatch lanes are
@@ -132,6 +144,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         poolNext = min(poolNext + (uint32_t)__popcll(idleMask), poolEnd);
       }
     }
+    stamp(tFetch);
     if (__ballot(active) == 0ull) {
       if (exhausted) break;
       continue;
@@ -226,11 +239,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       }
     }
 
+    stamp(tNode);
     // ---- leaf step: run only when enough lanes wait at a leaf, or when nobody has node work -------------------
     const uint64_t leafMask = __ballot(atLeaf);
     if (leafMask != 0ull) {
       const bool nodeWork = __ballot(atNode) != 0ull;
       if (__popcll(leafMask) >= (int)P.leafBatch || !nodeWork) {
+        if (COUNT) nLeafPhase++;
         if (atLeaf) {
           if (COUNT) wc.leaves++;
           if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
@@ -244,6 +259,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       }
     }
 
+    stamp(tLeaf);
     // ---- pop -------------------------------------------------------------------------------------------------------
     if (active && needPop) {
       bool finished = false;
@@ -267,10 +283,21 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         active = false;
       }
     }
+    stamp(tPop);
   }
 
   if (COUNT) {
     TraceCounters* c = P.counters;
+    if (lane_rank(~0ull) == 0u) { // one lane per wave reports the wave-uniform phase clocks
+      atomicAdd(&c->cyclesFetch, tFetch);
+      atomicAdd(&c->cyclesNode, tNode);
+      atomicAdd(&c->cyclesLeaf, tLeaf);
+      atomicAdd(&c->cyclesPop, tPop);
+      atomicAdd(&c->cyclesTotal, (unsigned long long)__builtin_readcyclecounter() - tBegin);
+      atomicAdd(&c->iterations, nIter);
+      atomicAdd(&c->leafPhases, nLeafPhase);
+      atomicAdd(&c->waves, 1ull);
+    }
     atomicAdd(&c->rays, wc.rays);
     atomicAdd(&c->nodeVisits, wc.nodes);
     atomicAdd(&c->leafVisits, wc.leaves);

@@ -60,7 +60,8 @@ class RTCAMDSceneStats(C.Structure):
 
 class RTCAMDTraceCounters(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in
-                ("rays", "nodeVisits", "leafVisits", "primTests", "innerVisits", "hits", "stackSpills", "reserved")]
+                ("rays", "nodeVisits", "leafVisits", "primTests", "innerVisits", "hits", "stackSpills", "reserved",
+                 "cyclesFetch", "cyclesNode", "cyclesLeaf", "cyclesPop", "cyclesTotal", "iterations", "leafPhases", "waves")]
 
 
 def load_library(path=LIB_PATH):

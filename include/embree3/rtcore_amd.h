@@ -59,6 +59,10 @@ struct RTCAMDTraceCounters
   unsigned long long hits;        /* rays that report a hit */
   unsigned long long stackSpills; /* pushes that overflowed the LDS stack into the HBM spill area */
   unsigned long long reserved;
+  /* shader-clock cycles summed over wavefronts, per phase of the traversal loop (the phases are wave-uniform):
+     ray fetch, inner-node step, leaf step, pop/finish, and the whole loop.  Diagnostic: where a batch spends time. */
+  unsigned long long cyclesFetch, cyclesNode, cyclesLeaf, cyclesPop, cyclesTotal;
+  unsigned long long iterations, leafPhases, waves; /* loop iterations, iterations that ran the leaf phase, waves */
 };
 RTC_API void rtcamdIntersect1MCounted(RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit* rayhit,
                                       unsigned int M, size_t byteStride, struct RTCAMDTraceCounters* counters);
