@@ -124,11 +124,27 @@ struct AccelDesc
   uint32_t blobStride;          // bytes per leaf blob (GridCell: 160; cBVH: header + nodes + leaves/grid)
 };
 
+// What one wavefront of an instrumented kernel reports (plain stores into its own slot: atomics on shared words
+// serialise in L2 at ~70 ns each and slow the very batch they are meant to describe).
+struct WaveRecord
+{
+  unsigned long long start, end;               // s_memrealtime ticks (100 MHz)
+  unsigned long long iterations, leafPhases, laneIters;
+  unsigned long long cyclesFetch, cyclesNode, cyclesLeaf, cyclesPop, cyclesTotal;
+  unsigned long long rays, nodes, leaves, prims, inner, hits, spills;
+  unsigned long long lastGrab, maxRaySteps;
+  unsigned long long valid;
+};
+static const uint32_t WAVE_LOG_CAPACITY = 16384; // wave records per launch (two launches per batch: triangles, subdiv)
+
 // Work counters of the instrumented kernels (mirrors RTCAMDTraceCounters).
 struct TraceCounters
 {
   unsigned long long rays, nodeVisits, leafVisits, primTests, innerVisits, hits, stackSpills, reserved;
   unsigned long long cyclesFetch, cyclesNode, cyclesLeaf, cyclesPop, cyclesTotal, iterations, leafPhases, waves;
+  unsigned long long activeLaneIters, startInv;
+  unsigned long long maxRaySteps, drainTicksSum, drainTicksMax;
+  unsigned long long waveEndHist[64], waveIterHist[64];
 };
 
 } // namespace rtamd

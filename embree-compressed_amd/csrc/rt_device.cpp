@@ -68,7 +68,7 @@ Device::Device(const char* cfg)
   numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   ownsStream = true;
-  HIP_CHECK(hipMalloc(&countersDev, sizeof(TraceCounters)));
+  HIP_CHECK(hipMalloc(&countersDev, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord)));
   HIP_CHECK(hipMalloc(&queuesDev, 64 * 32 * 4)); // TRACE_QUEUES heads, one 128-byte line each (TRACE_QUEUE_STRIDE)
   if (verbose >= 1)
     fprintf(stderr, "embree3-amd: device %d (%s, %d CUs), tri_accel=%s subdiv_accel=%s\n", gpu, prop.name, numCUs,

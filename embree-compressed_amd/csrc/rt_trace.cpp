@@ -25,7 +25,7 @@ static bool is_device_pointer(const void* p)
 }
 
 static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
-                      TraceCounters* dCounters)
+                      WaveRecord* dCounters)
 {
   Device* dev = s->device;
   if (A.kind == ACCEL_NONE || A.root == REF_EMPTY) return;
@@ -67,16 +67,20 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   const uint32_t instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
   const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
 
-  TraceCounters* dCounters = nullptr;
+  // instrumented twin: every wavefront stores one WaveRecord; first half of the log = triangle launch, second = subdiv
+  WaveRecord* dCounters = nullptr;
+  WaveRecord* dCounters2 = nullptr;
+  const size_t logBytes = 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord);
   if (countersOut) {
-    dCounters = (TraceCounters*)dev->countersDev;
-    HIP_CHECK(hipMemsetAsync(dCounters, 0, sizeof(TraceCounters), dev->stream));
+    dCounters = (WaveRecord*)dev->countersDev;
+    dCounters2 = dCounters + WAVE_LOG_CAPACITY;
+    HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, dev->stream));
   }
 
   if (is_device_pointer(rays)) {
     // device-resident stream: trace in place, stream-ordered, no host synchronisation
     launch_on(s, s->triAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
-    launch_on(s, s->subdivAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
+    launch_on(s, s->subdivAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2);
   } else {
     std::lock_guard<std::mutex> lock(dev->launchMutex);
     const size_t bytes = (size_t)M * rec;
@@ -87,7 +91,7 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
       for (uint32_t i = 0; i < M; i++) memcpy(h + (size_t)i * rec, (const char*)rays + (size_t)i * byteStride, rec);
     HIP_CHECK(hipMemcpyAsync(dev->stageDev, h, bytes, hipMemcpyHostToDevice, dev->stream));
     launch_on(s, s->triAccel, dev->stageDev, M, rec, occluded, instID, dCounters);
-    launch_on(s, s->subdivAccel, dev->stageDev, M, rec, occluded, instID, dCounters);
+    launch_on(s, s->subdivAccel, dev->stageDev, M, rec, occluded, instID, dCounters2);
     HIP_CHECK(hipMemcpyAsync(h, dev->stageDev, bytes, hipMemcpyDeviceToHost, dev->stream));
     HIP_CHECK(hipStreamSynchronize(dev->stream));
     // only tfar (byte 32) and the hit record (bytes 48..79) are outputs
@@ -100,8 +104,28 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   }
 
   if (countersOut) {
-    HIP_CHECK(hipMemcpyAsync(countersOut, dCounters, sizeof(TraceCounters), hipMemcpyDeviceToHost, dev->stream));
+    std::vector<WaveRecord> log(2 * (size_t)WAVE_LOG_CAPACITY);
+    HIP_CHECK(hipMemcpyAsync(log.data(), dCounters, logBytes, hipMemcpyDeviceToHost, dev->stream));
     HIP_CHECK(hipStreamSynchronize(dev->stream));
+    TraceCounters& c = *countersOut;
+    memset(&c, 0, sizeof(c));
+    unsigned long long first = ~0ull;
+    for (const WaveRecord& w : log)
+      if (w.valid) first = std::min(first, w.start);
+    c.startInv = ~first;
+    for (const WaveRecord& w : log) {
+      if (!w.valid) continue;
+      c.rays += w.rays; c.nodeVisits += w.nodes; c.leafVisits += w.leaves; c.primTests += w.prims;
+      c.innerVisits += w.inner; c.hits += w.hits; c.stackSpills += w.spills;
+      c.cyclesFetch += w.cyclesFetch; c.cyclesNode += w.cyclesNode; c.cyclesLeaf += w.cyclesLeaf; c.cyclesPop += w.cyclesPop;
+      c.cyclesTotal += w.cyclesTotal;
+      c.iterations += w.iterations; c.leafPhases += w.leafPhases; c.waves += 1; c.activeLaneIters += w.laneIters;
+      c.maxRaySteps = std::max(c.maxRaySteps, w.maxRaySteps);
+      c.drainTicksSum += w.end - w.lastGrab;
+      c.drainTicksMax = std::max(c.drainTicksMax, w.end - w.lastGrab);
+      c.waveEndHist[std::min<unsigned long long>((w.end - first) / 400ull, 63ull)] += 1; // 4 us buckets of 10 ns ticks
+      c.waveIterHist[std::min<unsigned long long>(w.iterations / 2ull, 63ull)] += 1;
+    }
   }
 }
 

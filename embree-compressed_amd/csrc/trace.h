@@ -18,7 +18,7 @@ struct LaunchParams
   uint32_t spillDepth; // entries per lane available in `spill`
   uint32_t gridBlocks; // persistent grid size the spill area was sized for
   uint32_t cbvhLevels; // fork: depth C of every cBVH blob of the scene (rtcSetSceneLevels)
-  TraceCounters* counters; // non-null selects the instrumented kernel twin
+  WaveRecord* counters;    // non-null selects the instrumented kernel twin; one record per wavefront
   uint32_t numCUs;         // compute units of the device (persistent grid sizing)
   uint32_t rayChunk;       // rays per work-queue grab (tuning knob, env RTAMD_CHUNK)
   uint32_t leafBatch;      // lanes waiting at a leaf before the leaf phase runs (tuning knob, env RTAMD_LEAF_BATCH)

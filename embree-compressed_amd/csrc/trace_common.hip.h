@@ -63,20 +63,17 @@ template <bool ROBUST> struct TravRay;
 template <> struct TravRay<true> // node_intersector1.h:108-129
 {
   float ox, oy, oz;
-  float rnx, rny, rnz; // rdir_near
-  float rfx, rfy, rfz; // rdir_far
+  float rnx, rny, rnz; // rdir_near; rdir_far = rdir_near*(1+3ulp) is re-derived per node (3 multiplies instead of 3 registers)
   bool negx, negy, negz;
   float tnear;
   __device__ __forceinline__ void init(const RayState& r)
   {
-    const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f; // 1+3*FLT_EPSILON
     ox = r.ox; oy = r.oy; oz = r.oz;
     // zero_fix: |d| < 1e-18 -> +1e-18 (vec3fa.h:163-165), then a true division
     const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx;
     const float zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy;
     const float zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
     rnx = 1.0f / zx; rny = 1.0f / zy; rnz = 1.0f / zz;
-    rfx = rnx * ulp3; rfy = rny * ulp3; rfz = rnz * ulp3;
     negx = !(rnx >= 0.0f); negy = !(rny >= 0.0f); negz = !(rnz >= 0.0f);
     tnear = fmaxf(r.tnear, 0.0f);
   }
@@ -86,6 +83,8 @@ template <> struct TravRay<true> // node_intersector1.h:108-129
   }
   __device__ __forceinline__ float farT(float px, float py, float pz) const
   {
+    const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f; // 1+3*FLT_EPSILON
+    const float rfx = rnx * ulp3, rfy = rny * ulp3, rfz = rnz * ulp3;
     return fminf(fminf((px - ox) * rfx, (py - oy) * rfy), (pz - oz) * rfz);
   }
 };

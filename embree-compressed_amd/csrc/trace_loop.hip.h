@@ -17,8 +17,9 @@
 // kernels/bvh/bvh_traverser1.h:549-666 with the tie rules of kernels/common/stack_item.h:39-80).
 //
 // A kernel is this skeleton instantiated with a Leaf policy:
-//   struct Leaf { template<bool OCCLUDED,bool COUNT> static __device__ bool intersect(const LaunchParams&, uint32_t ref, RayState&, WorkCounters&); }
-// returning true when an any-hit query is finished (ray occluded).
+//   struct Leaf { static __device__ void prepare();   // once per workgroup, before the loop (LDS tables)
+//                 template<bool OCCLUDED,bool COUNT> static __device__ bool intersect(const LaunchParams&, uint32_t ref, RayState&, WorkCounters&); }
+// intersect returns true when an any-hit query is finished (ray occluded).
 #pragma once
 #include "trace_common.hip.h"
 
@@ -31,6 +32,11 @@ namespace dev {
 // (<= 168 VGPRs, no scratch); the triangle kernels need 103 VGPRs and get 4 waves either way.
 #ifndef TRACE_MIN_WAVES_PER_SIMD
 #define TRACE_MIN_WAVES_PER_SIMD 3
+#endif
+// 1: the instrumented twin also reads the shader clock around every phase (cyclesFetch/Node/Leaf/Pop); the reads
+// serialise the scalar memory pipe and slow that twin down ~2x, so the default build leaves those four counters at 0
+#ifndef TRACE_PHASE_STAMPS
+#define TRACE_PHASE_STAMPS 0
 #endif
 static constexpr uint32_t RAY_CHUNK = 128;  // default rays a wave takes from a queue per atomic (LaunchParams::rayChunk)
 static constexpr uint32_t QUEUE_STRIDE = TRACE_QUEUE_STRIDE; // queue heads live in separate 128-byte lines
@@ -75,21 +81,29 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       if (COUNT) wc.spills++;
     }
   };
-  auto pop = [&](uint32_t slot) -> uint2 {
-    if (slot < (uint32_t)TRACE_LDS_STACK) return ldsStack[slot][tid];
-    return (slot - TRACE_LDS_STACK < P.spillDepth) ? spill[slot - TRACE_LDS_STACK] : make_uint2(REF_EMPTY, 0x7f800000u);
+  // overflow entries: nontemporal loads, so that the compiler keeps this rare global path apart from the LDS read
+  // (merged, both become one flat access with flat latency on every pop)
+  auto pop_spill = [&](uint32_t slot) -> uint2 {
+    if (!(slot - TRACE_LDS_STACK < P.spillDepth)) return make_uint2(REF_EMPTY, 0x7f800000u);
+    const uint32_t* e = (const uint32_t*)(spill + (slot - TRACE_LDS_STACK));
+    return make_uint2(__builtin_nontemporal_load(e), __builtin_nontemporal_load(e + 1));
   };
 
   // phase stamps of the instrumented twin: s_memtime around the wave-uniform phases (diagnostic only)
   unsigned long long tFetch = 0, tNode = 0, tLeaf = 0, tPop = 0, nIter = 0, nLeafPhase = 0, tStamp = 0, tBegin = 0;
   auto stamp = [&](unsigned long long& acc) {
-    if (COUNT) {
+    if (COUNT && TRACE_PHASE_STAMPS) {
       const unsigned long long now = __builtin_readcyclecounter();
       acc += now - tStamp;
       tStamp = now;
     }
   };
-  if (COUNT) tBegin = tStamp = __builtin_readcyclecounter();
+  unsigned long long laneIters = 0, rtBegin = 0, rtLastGrab = 0;
+  uint32_t raySteps = 0, maxRaySteps = 0;
+  if (COUNT) {
+    tBegin = tStamp = __builtin_readcyclecounter();
+    rtBegin = __builtin_amdgcn_s_memrealtime();
+  }
 
   for (;;) {
     if (COUNT) nIter++;
@@ -106,6 +120,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           if (laneId == 0u) base = atomicAdd(&queues[qCur * QUEUE_STRIDE], P.rayChunk);
           base = __builtin_amdgcn_readfirstlane(base);
           if (base < qHi - qLo) {
+            if (COUNT) rtLastGrab = __builtin_amdgcn_s_memrealtime();
             poolNext = qLo + base;
             poolEnd = min(poolNext + P.rayChunk, qHi);
             break;
@@ -132,7 +147,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           bool ok = r.tnear <= r.tfar;
           if (OCCLUDED) ok = ok && !(r.tfar < 0.0f);
           if (ok) {
-            if (COUNT) wc.rays++;
+            if (COUNT) { wc.rays++; raySteps = 0; }
             tr.init(r);
             travFar = fmaxf(r.tfar, 0.0f); // tray.tfar
             sp = 0;
@@ -145,6 +160,10 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       }
     }
     stamp(tFetch);
+    if (COUNT) {
+      laneIters += (unsigned long long)__popcll(__ballot(active));
+      if (active) { raySteps++; maxRaySteps = max(maxRaySteps, raySteps); }
+    }
     if (__ballot(active) == 0ull) {
       if (exhausted) break;
       continue;
@@ -195,58 +214,67 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
 #pragma unroll
         for (int j = 1; j < 8; j++) c = (k == j) ? cref[j] : c;
         cur = c;
-      } else if (OCCLUDED) {
-        // traverseAnyHit (bvh_traverser1.h:638-666): descend into the highest-index hit child, stack the rest
-        // in ascending index order, no sorting.
-        uint32_t slot = sp;
-        uint32_t last = REF_EMPTY;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (mask & (1u << k)) {
-            if (last != REF_EMPTY) { push(last, 0u, slot); slot++; }
-            last = cref[k];
-          }
-        }
-        sp = slot;
-        cur = last;
       } else {
-        // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
-        // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80).  rank[k] = #children visited before k.
+        // rank[k] = number of hit children visited before child k; rank 0 is entered now, the others are stacked
+        // so that they pop in rank order.
         uint32_t rank[8];
+        if (OCCLUDED) {
+          // traverseAnyHit (bvh_traverser1.h:638-666): descend into the highest-index hit child, stack the rest
+          // in ascending index order, no sorting
 #pragma unroll
-        for (int k = 0; k < 8; k++) rank[k] = 0;
+          for (int k = 0; k < 8; k++) rank[k] = (uint32_t)__popc(mask >> (k + 1));
+        } else {
+          // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
+          // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80); non-hit children carry 0xFFFFFFFF
+          // and sort behind every hit child
 #pragma unroll
-        for (int a = 0; a < 8; a++) {
+          for (int k = 0; k < 8; k++) rank[k] = 0;
 #pragma unroll
-          for (int b = a + 1; b < 8; b++) {
-            const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u; // tie -> b (higher index) first
-            rank[b] += aFirst;
-            rank[a] += 1u - aFirst;
+          for (int a = 0; a < 8; a++) {
+#pragma unroll
+            for (int b = a + 1; b < 8; b++) {
+              const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u; // tie -> b (higher index) first
+              rank[b] += aFirst;
+              rank[a] += 1u - aFirst;
+            }
           }
         }
-        // non-hit children carry 0xFFFFFFFF and sort behind every hit child (among themselves irrelevant)
-        const uint32_t base = sp + (uint32_t)nhit - 1u;
+        const uint32_t top = sp + (uint32_t)nhit - 1u;
         uint32_t next = REF_EMPTY;
+        if (top <= (uint32_t)TRACE_LDS_STACK) {
+          // common case, branch-free: every entry lands in LDS; children that are not stacked write to the scratch row
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          if (mask & (1u << k)) {
-            if (rank[k] == 0) next = cref[k];
-            else push(cref[k], dist[k], base - rank[k]);
+          for (int k = 0; k < 8; k++) {
+            const bool h = (mask >> k) & 1u;
+            const bool stacked = h && rank[k] != 0u;
+            next = (h && rank[k] == 0u) ? cref[k] : next;
+            ldsStack[stacked ? top - rank[k] : (uint32_t)TRACE_LDS_STACK][tid] = make_uint2(cref[k], dist[k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            if (mask & (1u << k)) {
+              if (rank[k] == 0u) next = cref[k];
+              else push(cref[k], dist[k], top - rank[k]);
+            }
           }
         }
-        sp = base;
+        sp = top;
         cur = next;
       }
     }
 
     stamp(tNode);
     // ---- leaf step: run only when enough lanes wait at a leaf, or when nobody has node work -------------------
-    const uint64_t leafMask = __ballot(atLeaf);
+    // (lanes whose node step just ended at a leaf count as waiting: they need no extra iteration to get there)
+    const bool atLeafNow = active && !needPop && (cur & REF_LEAF);
+    const bool atNodeNext = active && !needPop && !(cur & REF_LEAF);
+    const uint64_t leafMask = __ballot(atLeafNow);
     if (leafMask != 0ull) {
-      const bool nodeWork = __ballot(atNode) != 0ull;
+      const bool nodeWork = __ballot(atNodeNext) != 0ull;
       if (__popcll(leafMask) >= (int)P.leafBatch || !nodeWork) {
         if (COUNT) nLeafPhase++;
-        if (atLeaf) {
+        if (atLeafNow) {
           if (COUNT) wc.leaves++;
           if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
             r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
@@ -266,7 +294,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       for (;;) {
         if (sp == 0) { finished = true; break; }
         sp--;
-        const uint2 e = pop(sp);
+        uint2 e;
+        if (sp < (uint32_t)TRACE_LDS_STACK) e = ldsStack[sp][tid];
+        else e = pop_spill(sp);
         if (e.x == REF_EMPTY) continue;                           // entry lost to an exhausted spill area
         if (!OCCLUDED && __uint_as_float(e.y) > r.tfar) continue; // bvh_intersector1.cpp:86
         cur = e.x;
@@ -287,31 +317,36 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   }
 
   if (COUNT) {
-    TraceCounters* c = P.counters;
-    if (lane_rank(~0ull) == 0u) { // one lane per wave reports the wave-uniform phase clocks
-      atomicAdd(&c->cyclesFetch, tFetch);
-      atomicAdd(&c->cyclesNode, tNode);
-      atomicAdd(&c->cyclesLeaf, tLeaf);
-      atomicAdd(&c->cyclesPop, tPop);
-      atomicAdd(&c->cyclesTotal, (unsigned long long)__builtin_readcyclecounter() - tBegin);
-      atomicAdd(&c->iterations, nIter);
-      atomicAdd(&c->leafPhases, nLeafPhase);
-      atomicAdd(&c->waves, 1ull);
+    // per-lane work counters are reduced over the wave; lane 0 stores the wave's record into its own slot
+    unsigned long long v[7] = {wc.rays, wc.nodes, wc.leaves, wc.prims, wc.inner, wc.hits, wc.spills};
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxRaySteps = max(maxRaySteps, (uint32_t)__shfl_xor((int)maxRaySteps, off, 64));
+    const uint32_t waveIdx = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
+    if (laneId == 0u && waveIdx < WAVE_LOG_CAPACITY) {
+      WaveRecord rec;
+      rec.start = rtBegin;
+      rec.end = __builtin_amdgcn_s_memrealtime();
+      rec.iterations = nIter; rec.leafPhases = nLeafPhase; rec.laneIters = laneIters;
+      rec.cyclesFetch = tFetch; rec.cyclesNode = tNode; rec.cyclesLeaf = tLeaf; rec.cyclesPop = tPop;
+      rec.cyclesTotal = (unsigned long long)__builtin_readcyclecounter() - tBegin;
+      rec.rays = v[0]; rec.nodes = v[1]; rec.leaves = v[2]; rec.prims = v[3]; rec.inner = v[4]; rec.hits = v[5]; rec.spills = v[6];
+      rec.lastGrab = rtLastGrab ? rtLastGrab : rtBegin;
+      rec.maxRaySteps = maxRaySteps;
+      rec.valid = 1ull;
+      P.counters[waveIdx] = rec;
     }
-    atomicAdd(&c->rays, wc.rays);
-    atomicAdd(&c->nodeVisits, wc.nodes);
-    atomicAdd(&c->leafVisits, wc.leaves);
-    atomicAdd(&c->primTests, wc.prims);
-    atomicAdd(&c->innerVisits, wc.inner);
-    atomicAdd(&c->hits, wc.hits);
-    atomicAdd(&c->stackSpills, wc.spills);
   }
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES_PER_SIMD) void trace_kernel(LaunchParams P)
 {
-  __shared__ uint2 ldsStack[TRACE_LDS_STACK][TRACE_BLOCK];
+  __shared__ uint2 ldsStack[TRACE_LDS_STACK + 1][TRACE_BLOCK]; // + one scratch row for the branch-free pushes
+  Leaf::prepare();
   trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack);
 }
 

@@ -69,6 +69,8 @@ __device__ __forceinline__ bool pluecker_rel(const RayState& r, const RelV a, co
 
 struct GridCellLeaf
 {
+  static __device__ __forceinline__ void prepare() {}
+
   template <bool OCCLUDED, bool COUNT>
   static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
   {
@@ -140,8 +142,30 @@ struct GridCellLeaf
 // ---------------------------------------------------------------------------------------------------
 enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2 };
 
+// Node decode tables (compressed_node.h:488-510): border planes, mid planes, and their complements 1-x (the same
+// fp32 subtraction the reference performs per decode, done once).  They live in LDS: a lookup is one ds_read (~100
+// cycles) instead of a global load per plane; with eight lookups per node and up to five dependent levels per blob the
+// global-memory version put several extra L1/L2 round trips on every ray's critical path.
 __constant__ float c_tblBorder[8] = {0.000f, 0.005f, 0.010f, 0.050f, 0.100f, 0.200f, 0.400f, 0.600f};
 __constant__ float c_tblMid[8] = {0.00f, 0.40f, 0.48f, 0.49f, 0.50f, 0.51f, 0.52f, 0.60f};
+enum { TBL_BORDER = 0, TBL_MID = 8, TBL_ONE_MINUS_MID = 16, TBL_ONE_MINUS_BORDER = 24 };
+__device__ __forceinline__ float* cbvh_tables()
+{
+  __shared__ float tbl[32];
+  return tbl;
+}
+__device__ __forceinline__ void cbvh_tables_init()
+{
+  float* t = cbvh_tables();
+  if (threadIdx.x < 8) {
+    const float b = c_tblBorder[threadIdx.x], m = c_tblMid[threadIdx.x];
+    t[TBL_BORDER + threadIdx.x] = b;
+    t[TBL_MID + threadIdx.x] = m;
+    t[TBL_ONE_MINUS_MID + threadIdx.x] = 1.f - m;
+    t[TBL_ONE_MINUS_BORDER + threadIdx.x] = 1.f - b;
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ uint32_t compact1by1(uint32_t x)
 {
@@ -278,9 +302,10 @@ __device__ __forceinline__ bool grid_triangle(const float* v0, const float* v1, 
   return false;
 }
 
+// `zz` (leaf mode): the cell's two height bytes, z12 in bits 0..7 and z34 in bits 8..15
 template <int MODE, bool COUNT>
-__device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, float tN, float tF, float blx, float bly, float blz, float bhx,
-                                          float bhy, float bhz, WorkCounters& wc)
+__device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz, float tN, float tF, float blx, float bly, float blz,
+                                          float bhx, float bhy, float bhz, WorkCounters& wc)
 {
   if (MODE == MODE_LEAF) { // compressed.h:539-593
     if (tN >= c.tfar) return;
@@ -289,7 +314,7 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, float tN, fl
     const float dz = 0.0625f * range; // getDelta() = rcp(16) (compressed_leaf.h:109-111)
     const float rcpF = 0.0625f * range;
     const float off = blz - dimZ * c.extent;
-    const uint32_t z12 = c.leaves[2 * idx], z34 = c.leaves[2 * idx + 1];
+    const uint32_t z12 = zz & 0xffu, z34 = (zz >> 8) & 0xffu;
     const float z1 = off + rcpF * (float)(z12 >> 4), z2 = off + rcpF * (float)(z12 & 0xf);
     const float z3 = off + rcpF * (float)(z34 >> 4), z4 = off + rcpF * (float)(z34 & 0xf);
     float u, v, t = c.tfar;
@@ -329,23 +354,37 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, float tN, fl
   }
 }
 
-// One inner node with REM levels below it (REM == 1: its children are cells).
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// One inner node with REM levels below it (REM == 1: its children are cells); `w` is the node's word (bytes xz, x,
+// yz, y).  The four children of node `curr` are the consecutive words 4*curr+1 .. 4*curr+4 (or, below the last inner
+// level, the consecutive 2-byte cells 4*curr+1-elems ..): they are requested with ONE load as soon as the node is
+// entered, so the round trip overlaps the decode and the slab test of this node instead of following them per child.
 template <int MODE, int REM, bool COUNT>
-__device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, float blx, float bly, float blz, float bhx, float bhy, float bhz,
-                                          WorkCounters& wc)
+__device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w, float blx, float bly, float blz, float bhx, float bhy,
+                                          float bhz, WorkCounters& wc)
 {
-  const uint32_t w = c.nodes[curr]; // bytes xz, x, yz, y
+  uint32_t cw[4] = {0u, 0u, 0u, 0u};
+  if constexpr (REM > 1) {
+    const u32x4_a4 q = *(const u32x4_a4*)(c.nodes + (4u * curr + 1u));
+    cw[0] = q.x; cw[1] = q.y; cw[2] = q.z; cw[3] = q.w;
+  } else if constexpr (MODE == MODE_LEAF) {
+    const u32x2_a4 q = *(const u32x2_a4*)(c.leaves + 2u * (4u * curr + 1u - c.elems)); // 4 cells x 2 bytes
+    cw[0] = q.x; cw[1] = q.y;
+  }
   if (COUNT) wc.inner++;
   // getNode, compressed_node.h:488-510
   const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
-  const float lx0 = c_tblBorder[(w >> 5) & 7] * dimX + blx;          // X1: children 0,2 lower
-  const float lx1 = c_tblMid[(w >> 2) & 7] * dimX + blx;             // X2: children 1,3 lower
-  const float ux0 = (1.f - c_tblMid[(w >> 13) & 7]) * dimX + blx;    // X3: children 0,2 upper
-  const float ux1 = (1.f - c_tblBorder[(w >> 10) & 7]) * dimX + blx; // X4: children 1,3 upper
-  const float ly0 = c_tblBorder[(w >> 21) & 7] * dimY + bly;         // Y1: children 0,1 lower
-  const float ly1 = c_tblMid[(w >> 18) & 7] * dimY + bly;            // Y2: children 2,3 lower
-  const float uy0 = (1.f - c_tblMid[(w >> 29) & 7]) * dimY + bly;    // Y3: children 0,1 upper
-  const float uy1 = (1.f - c_tblBorder[(w >> 26) & 7]) * dimY + bly; // Y4: children 2,3 upper
+  const float* T = cbvh_tables();
+  const float lx0 = T[TBL_BORDER + ((w >> 5) & 7)] * dimX + blx;            // X1: children 0,2 lower
+  const float lx1 = T[TBL_MID + ((w >> 2) & 7)] * dimX + blx;               // X2: children 1,3 lower
+  const float ux0 = T[TBL_ONE_MINUS_MID + ((w >> 13) & 7)] * dimX + blx;    // X3: children 0,2 upper
+  const float ux1 = T[TBL_ONE_MINUS_BORDER + ((w >> 10) & 7)] * dimX + blx; // X4: children 1,3 upper
+  const float ly0 = T[TBL_BORDER + ((w >> 21) & 7)] * dimY + bly;           // Y1: children 0,1 lower
+  const float ly1 = T[TBL_MID + ((w >> 18) & 7)] * dimY + bly;              // Y2: children 2,3 lower
+  const float uy0 = T[TBL_ONE_MINUS_MID + ((w >> 29) & 7)] * dimY + bly;    // Y3: children 0,1 upper
+  const float uy1 = T[TBL_ONE_MINUS_BORDER + ((w >> 26) & 7)] * dimY + bly; // Y4: children 2,3 upper
   const float lz = (float)(w & 3) * 0.25f * dimZ + blz;              // table3 = k/4
   const float uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
 
@@ -386,18 +425,23 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, float blx, 
     const float cbx0 = (rr & 1) ? lx1 : lx0, cbx1 = (rr & 1) ? ux1 : ux0;
     const float cby0 = (rr & 2) ? ly1 : ly0, cby1 = (rr & 2) ? uy1 : uy0;
     const uint32_t child = 4u * curr + 1u + (uint32_t)rr;
+    uint32_t cword;
+    if constexpr (REM == 1) cword = ((rr & 2) ? cw[1] : cw[0]) >> ((rr & 1) * 16);
+    else cword = rr == 0 ? cw[0] : rr == 1 ? cw[1] : rr == 2 ? cw[2] : cw[3];
     if constexpr (REM == 1) {
       float tn = tN[0], tf = tF[0];
 #pragma unroll
       for (int q = 1; q < 4; q++) { tn = rr == q ? tN[q] : tn; tf = rr == q ? tF[q] : tf; }
-      cbvh_cell<MODE, COUNT>(c, child - c.elems, tn, tf, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+      cbvh_cell<MODE, COUNT>(c, child - c.elems, cword, tn, tf, cbx0, cby0, lz, cbx1, cby1, uz, wc);
     } else
-      cbvh_node<MODE, REM - 1, COUNT>(c, child, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+      cbvh_node<MODE, REM - 1, COUNT>(c, child, cword, cbx0, cby0, lz, cbx1, cby1, uz, wc);
   }
 }
 
 template <int MODE, int LEVELS> struct CbvhLeaf
 {
+  static __device__ __forceinline__ void prepare() { cbvh_tables_init(); }
+
   template <bool OCCLUDED, bool COUNT>
   static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
   {
@@ -422,6 +466,7 @@ template <int MODE, int LEVELS> struct CbvhLeaf
     CbvhCtx c;
     c.H = H;
     c.nodes = (const uint32_t*)(blob + CBVH_HEADER_BYTES);
+    const uint32_t rootWord = c.nodes[0]; // requested together with the header: no extra round trip after the frustum test
     c.elems = H->elems;
     c.leaves = blob + CBVH_HEADER_BYTES + 4u * c.elems;
     c.grid = (const float*)(blob + CBVH_HEADER_BYTES + 4u * c.elems);
@@ -491,7 +536,7 @@ template <int MODE, int LEVELS> struct CbvhLeaf
       c.negx = !(c.rnx >= 0.f); c.negy = !(c.rny >= 0.f); c.negz = !(c.rnz >= 0.f);
     }
     // root: local frame box xy in [-1,1], z from the leaf data (:517-519)
-    cbvh_node<MODE, LEVELS, COUNT>(c, 0u, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);
+    cbvh_node<MODE, LEVELS, COUNT>(c, 0u, rootWord, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);
     return false;
   }
 };

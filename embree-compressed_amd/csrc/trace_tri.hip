@@ -8,8 +8,15 @@
 namespace rtamd {
 namespace dev {
 
+// Records requested per memory round trip inside a block of 4 (1, 2 or 4): more hides latency, fewer saves registers.
+#ifndef TRI_FETCH
+#define TRI_FETCH 4
+#endif
+
 template <bool PLUECKER> struct TriLeaf
 {
+  static __device__ __forceinline__ void prepare() {}
+
   template <bool OCCLUDED, bool COUNT>
   static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
   {
@@ -23,20 +30,30 @@ template <bool PLUECKER> struct TriLeaf
       TriHit best;
       uint32_t bestPrim = 0, bestGeom = 0;
       best.t = RT_INF;
-      for (uint32_t k = 0; k < nb; k++) {
-        const float4* tp = (const float4*)(prims + first + b + k);
-        const float4 A = tp[0], B = tp[1], C = tp[2];
-        if (COUNT) wc.prims++;
-        TriHit h;
-        const bool ok = PLUECKER ? pluecker(r, A, B, C, tfarBlock, h) : moeller(r, A, B, C, tfarBlock, h);
-        if (ok) {
-          if (OCCLUDED) return true; // Occluded1EpilogM: any valid lane (no ray mask, no filter)
-          // select_min over valid lanes, lowest lane wins ties (vfloat4_sse2.h:654-659)
-          if (!found || h.t < best.t) {
-            best = h;
-            bestGeom = __float_as_uint(A.w);
-            bestPrim = __float_as_uint(B.w);
-            found = true;
+      // all records of the block are requested before the first one is used (one memory round trip per block instead
+      // of one per triangle); slots past the leaf end re-read the last record and are skipped below
+      for (uint32_t g = 0; g < nb; g += TRI_FETCH) {
+        float4 A[TRI_FETCH], B[TRI_FETCH], C[TRI_FETCH];
+#pragma unroll
+        for (uint32_t k = 0; k < TRI_FETCH; k++) {
+          const float4* tp = (const float4*)(prims + first + b + min(g + k, nb - 1u));
+          A[k] = tp[0]; B[k] = tp[1]; C[k] = tp[2];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < TRI_FETCH; k++) {
+          if (g + k >= nb) break;
+          if (COUNT) wc.prims++;
+          TriHit h;
+          const bool ok = PLUECKER ? pluecker(r, A[k], B[k], C[k], tfarBlock, h) : moeller(r, A[k], B[k], C[k], tfarBlock, h);
+          if (ok) {
+            if (OCCLUDED) return true; // Occluded1EpilogM: any valid lane (no ray mask, no filter)
+            // select_min over valid lanes, lowest lane wins ties (vfloat4_sse2.h:654-659)
+            if (!found || h.t < best.t) {
+              best = h;
+              bestGeom = __float_as_uint(A[k].w);
+              bestPrim = __float_as_uint(B[k].w);
+              found = true;
+            }
           }
         }
       }

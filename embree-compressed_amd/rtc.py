@@ -61,7 +61,8 @@ class RTCAMDSceneStats(C.Structure):
 class RTCAMDTraceCounters(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in
                 ("rays", "nodeVisits", "leafVisits", "primTests", "innerVisits", "hits", "stackSpills", "reserved",
-                 "cyclesFetch", "cyclesNode", "cyclesLeaf", "cyclesPop", "cyclesTotal", "iterations", "leafPhases", "waves")]
+                 "cyclesFetch", "cyclesNode", "cyclesLeaf", "cyclesPop", "cyclesTotal", "iterations", "leafPhases", "waves",
+                 "activeLaneIters", "startInv", "maxRaySteps", "drainTicksSum", "drainTicksMax")] + [("waveEndHist", C.c_ulonglong * 64), ("waveIterHist", C.c_ulonglong * 64)]
 
 
 def load_library(path=LIB_PATH):
@@ -313,7 +314,7 @@ class Scene:
         cnt = RTCAMDTraceCounters()
         self.lib.rtcamdIntersect1MCounted(self.handle, C.byref(ctx), ptr, m, stride, C.byref(cnt))
         self.device.check("rtcamdIntersect1MCounted")
-        return {n: getattr(cnt, n) for n, _ in RTCAMDTraceCounters._fields_}
+        return {n: (list(getattr(cnt, n)) if n.endswith("Hist") else getattr(cnt, n)) for n, _ in RTCAMDTraceCounters._fields_}
 
     def stats(self):
         st = RTCAMDSceneStats()

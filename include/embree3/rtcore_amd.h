@@ -63,6 +63,14 @@ struct RTCAMDTraceCounters
      ray fetch, inner-node step, leaf step, pop/finish, and the whole loop.  Diagnostic: where a batch spends time. */
   unsigned long long cyclesFetch, cyclesNode, cyclesLeaf, cyclesPop, cyclesTotal;
   unsigned long long iterations, leafPhases, waves; /* loop iterations, iterations that ran the leaf phase, waves */
+  /* wave timeline (100 MHz s_memrealtime): lanes with a ray summed over iterations (/(64*iterations) = occupancy of the
+     loop), ~(earliest wave start), and two per-wave histograms: end time since the earliest start in 4 us buckets,
+     and iterations per wave in buckets of 2.  Diagnostic: how long the drain of a batch is. */
+  unsigned long long activeLaneIters, startInv;
+  /* longest single ray in loop iterations (node steps + leaf steps + waiting), and the drain of the waves: time from a
+     wave's last successful work-queue grab to its end, summed over waves / maximum (10 ns ticks) */
+  unsigned long long maxRaySteps, drainTicksSum, drainTicksMax;
+  unsigned long long waveEndHist[64], waveIterHist[64];
 };
 RTC_API void rtcamdIntersect1MCounted(RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit* rayhit,
                                       unsigned int M, size_t byteStride, struct RTCAMDTraceCounters* counters);
