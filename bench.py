@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--levels", default="6,3", help="subdivision level, compression level")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-others", action="store_true", help="skip the short tri / eager side runs")
+    ap.add_argument("--inflight", type=int, default=4,
+                    help="ray batches in flight: step s is enqueued on HIP stream s %% inflight (1 = one stream, strictly back-to-back)")
     ap.add_argument("--rays-kind", default="random", choices=["random", "primary"],
                     help="random: the metric's incoherent bbox rays; primary: BASELINE config 4, 1920x1080 camera rays of bomberman.ecs")
     return ap.parse_args()
@@ -124,26 +126,41 @@ def cpu_baseline(sc, rtc, workload, mesh, levels, lo, hi, m, budget_s):
             "sample": f"{reps} x {m} rays of the same generator (seed 12345), {what} (oracle/liboracle.so), {cores} pthreads, blocks of 1024"}
 
 
-def run_loop(torch, dist, sc, dev, stream, bufs, K, W, world):
+def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world):
+    """W untimed + K timed steps; step s goes to streams[s % len(streams)] (the library keeps per-launch scratch, so
+    batches on different streams overlap: the drain of one batch runs under the start of the next).  Returns the
+    host-clock time of the timed region and, for ONE stream, the HIP-event time per launch on that stream."""
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    for s in range(W):
+    def step(s):
+        st = streams[s % len(streams)]
+        dev.set_stream(st.cuda_stream)
         sc.intersect1M(bufs[s], check=False)
+
+    # every stream (and every per-launch context of the library) is exercised before the clock starts: first use of a
+    # HIP stream costs milliseconds.  The extra untimed steps re-trace warm-up batches, never timed ones.
+    for s in range(W):
+        step(s)
+    for s in range(W, 2 * len(streams) if len(streams) > 1 else 0):
+        st = streams[s % len(streams)]
+        dev.set_stream(st.cuda_stream)
+        sc.intersect1M(bufs[s % max(W, 1)], check=False)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record(stream)
+    ev0.record(streams[0])
     for s in range(W, W + K):
-        sc.intersect1M(bufs[s], check=False)
-    ev1.record(stream)
+        step(s)
+    ev1.record(streams[0])
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
     dev.check("timed region")
-    return t1 - t0, ev0.elapsed_time(ev1) / K  # host-clock region, HIP-event ms per launch on the launch stream
+    dev.set_stream(streams[0].cuda_stream)
+    return t1 - t0, (ev0.elapsed_time(ev1) / K if len(streams) == 1 else None)
 
 
 def main():
@@ -169,7 +186,9 @@ def main():
     lo, hi = mesh[0].min(0), mesh[0].max(0)  # bbox of the control vertices, like prepareRandomRays (viewer_device.cpp:394-429)
     levels = tuple(int(x) for x in args.levels.split(","))
 
-    stream = torch.cuda.Stream()
+    nfl = max(1, args.inflight)
+    streams = [torch.cuda.Stream() for _ in range(nfl)]
+    stream = streams[0]
     torch.cuda.set_stream(stream)
     m, K, W = args.rays, args.steps, args.warmup
     primary = None
@@ -181,17 +200,24 @@ def main():
         dev, sc = build_scene(rtc, local_rank, workload, mesh, levels)
         dev.set_stream(stream.cuda_stream)
         # distinct batches per step and per rank, generated on the host, resident in HBM before timing starts
+        nb = 2 * (K + W) + 1 if nfl > 1 else K + W + 1
         if primary is not None:  # the same camera frame every step, but a fresh copy (a trace modifies rays in place)
-            bufs = [torch.from_numpy(primary).to("cuda") for s in range(K + W + 1)]
+            bufs = [torch.from_numpy(primary).to("cuda") for s in range(nb)]
         else:
-            bufs = [torch.from_numpy(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))).to("cuda") for s in range(K + W + 1)]
+            bufs = [torch.from_numpy(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))).to("cuda") for s in range(nb)]
         torch.cuda.synchronize()
-        cnt = sc.intersect1M_counted(bufs[K + W])  # extra batch: work counters -> algorithmic bytes per ray
-        elapsed, kernel_ms = run_loop(torch, dist, sc, dev, stream, bufs, K, W, world)
+        cnt = sc.intersect1M_counted(bufs[nb - 1])  # extra batch: work counters -> algorithmic bytes per ray
+        # pass 1, one stream: the kernel alone, HIP-event time per launch (the roofline figure; agrees with rocprofv3
+        # --kernel-trace of `bench.py --inflight 1`)
+        elapsed1, kernel_ms = run_loop(torch, dist, sc, dev, streams[:1], bufs, K, W, world)
         hits = int((bufs[W].view(torch.int32)[:, 18] != -1).sum().item())
-        return dev, sc, cnt, elapsed, kernel_ms, hits
+        # pass 2 (the reported value), fresh batches: `inflight` batches in flight on as many streams
+        elapsed = elapsed1
+        if nfl > 1:
+            elapsed, _ = run_loop(torch, dist, sc, dev, streams, bufs[K + W:], K, W, world)
+        return dev, sc, cnt, elapsed, kernel_ms, hits, elapsed1
 
-    dev, sc, cnt, elapsed, kernel_ms, hits = measure(args.workload, K, W)
+    dev, sc, cnt, elapsed, kernel_ms, hits, elapsed1 = measure(args.workload, K, W)
     st = sc.stats()
     rate, worst = D.whole_job_rate(m * K, elapsed, world, device="cuda")
     n_node = cnt["nodeVisits"] / max(cnt["rays"], 1)
@@ -225,9 +251,14 @@ def main():
                                    + "rtcIntersect1M on device-resident RTCRayHit[80B]",
                        "rays_per_step_per_gpu": m, "accel_kind": st["accelKind"], "bvh_nodes": st["nodeCount"], "leaf_records": st["primCount"],
                        "leaf_record_bytes": st["primBytes"], "accel_bytes": st["totalBytes"], "hits_first_timed_batch": hits,
+                       "batches_in_flight": nfl,
+                       "in_flight_note": (f"step s is enqueued on HIP stream s % {nfl}; value = K steps / wall time of the region. "
+                                          "One stream, strictly back-to-back (the roofline pass of this same run): "
+                                          f"{m * K / elapsed1 / 1e6:.1f} Mrays/s on this rank") if nfl > 1 else "one stream, strictly back-to-back",
                        "sharding": f"replicated accel, {world} independent ray shards, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "kernel": tag,
+                         "aggregate_frac_in_flight": bytes_per_ray * m * K / elapsed / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "leaf_visits_per_ray": n_prim,
                          "inner_steps_per_ray": n_inner, "node_bytes": st["nodeBytes"], "leaf_bytes": st["primBytes"]},
         }
@@ -239,7 +270,7 @@ def main():
     if world == 1 and not args.no_others and args.workload == "cbvh.leaf":
         others = {}
         for w2 in ("tri", "eager"):
-            d2, s2, c2, e2, k2, h2 = measure(w2, 5, 2)
+            d2, s2, c2, e2, k2, h2, _ = measure(w2, 5, 2)
             others[w2] = {"Mrays_per_s": m * 5 / e2 / 1e6, "kernel_ms": k2, "hits": h2, "steps": 5}
             s2.release()
             d2.release()

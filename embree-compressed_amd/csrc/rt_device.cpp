@@ -69,7 +69,10 @@ Device::Device(const char* cfg)
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   ownsStream = true;
   HIP_CHECK(hipMalloc(&countersDev, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord)));
-  HIP_CHECK(hipMalloc(&queuesDev, 64 * 32 * 4)); // TRACE_QUEUES heads, one 128-byte line each (TRACE_QUEUE_STRIDE)
+  for (LaunchCtx& c : launchCtx) {
+    HIP_CHECK(hipMalloc(&c.queues, 64 * 32 * 4)); // TRACE_QUEUES heads, one 128-byte line each (TRACE_QUEUE_STRIDE)
+    HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  }
   if (verbose >= 1)
     fprintf(stderr, "embree3-amd: device %d (%s, %d CUs), tri_accel=%s subdiv_accel=%s\n", gpu, prop.name, numCUs,
             tri_accel.c_str(), subdiv_accel.c_str());
@@ -85,9 +88,15 @@ Device::~Device()
   }
   if (stageHost) hipHostFree(stageHost);
   if (stageDev) hipFree(stageDev);
-  if (spillDev) hipFree(spillDev);
+  for (LaunchCtx& c : launchCtx) {
+    if (c.done) {
+      if (c.used) hipEventSynchronize(c.done);
+      hipEventDestroy(c.done);
+    }
+    if (c.spill) hipFree(c.spill);
+    if (c.queues) hipFree(c.queues);
+  }
   if (countersDev) hipFree(countersDev);
-  if (queuesDev) hipFree(queuesDev);
 }
 
 void Device::useDevice() const
@@ -144,17 +153,37 @@ void Device::ensureStaging(size_t bytes)
   stageBytes = want;
 }
 
-void Device::ensureSpill(size_t bytes)
+Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded)
 {
-  if (bytes <= spillBytes) return;
-  if (spillDev) {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    hipFree(spillDev);
-    spillDev = nullptr;
-    spillBytes = 0;
+  std::lock_guard<std::mutex> lock(ctxMutex);
+  // first context whose last kernel has finished (back-to-back batches on one stream then cycle through two or three
+  // contexts, and only those get a spill area); all busy: take the next one in turn and wait for it on the stream
+  LaunchCtx* pick = nullptr;
+  for (LaunchCtx& k : launchCtx) {
+    if (!k.used) { pick = &k; break; }
+    const hipError_t q = hipEventQuery(k.done);
+    if (q == hipSuccess) { k.used = false; pick = &k; break; }
+    if (q != hipErrorNotReady) HIP_CHECK(q);
   }
-  HIP_CHECK(hipMalloc(&spillDev, bytes));
-  spillBytes = bytes;
+  (void)hipGetLastError(); // hipErrorNotReady is not an error
+  LaunchCtx& c = pick ? *pick : launchCtx[nextCtx++ % NUM_LAUNCH_CTX];
+  if (spillBytesNeeded > c.spillBytes) {
+    // grow the overflow areas of ALL contexts now (first batch after a commit with a deeper tree): an allocation
+    // synchronises the device, so it must not happen again when the next context is first used in the middle of a
+    // pipelined sequence of batches
+    HIP_CHECK(hipDeviceSynchronize());
+    for (LaunchCtx& k : launchCtx) {
+      if (k.spill) hipFree(k.spill);
+      k.spill = nullptr;
+      k.spillBytes = 0;
+      HIP_CHECK(hipMalloc(&k.spill, spillBytesNeeded));
+      k.spillBytes = spillBytesNeeded;
+      k.used = false;
+    }
+  }
+  if (c.used) HIP_CHECK(hipStreamWaitEvent(stream, c.done, 0));
+  c.used = true;
+  return c;
 }
 
 // ---- Buffer ------------------------------------------------------------------------------------------

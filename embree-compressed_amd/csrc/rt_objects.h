@@ -46,11 +46,23 @@ struct Device : RefCounted
   void* stageDev = nullptr;
   size_t stageBytes = 0;
 
-  // LDS-stack overflow area and counters scratch, sized at first launch
-  void* spillDev = nullptr;
-  size_t spillBytes = 0;
-  void* countersDev = nullptr;
-  void* queuesDev = nullptr; // 8 x u32 work-queue heads of the persistent kernels
+  // Per-launch scratch (work-queue heads + LDS-stack overflow area).  A ring of contexts, so that batches enqueued on
+  // DIFFERENT streams (rtcamdSetDeviceStream between calls) can be in flight together: the drain of one batch - a few
+  // deep rays keeping waves alive - then overlaps the start of the next.  A context is reused only after the kernel
+  // that last used it has finished (stream-side wait on its event, no host block).
+  struct LaunchCtx
+  {
+    void* queues = nullptr;  // TRACE_QUEUES heads, one 128-byte line each
+    void* spill = nullptr;
+    size_t spillBytes = 0;
+    hipEvent_t done = nullptr;
+    bool used = false;
+  };
+  static const int NUM_LAUNCH_CTX = 8;
+  LaunchCtx launchCtx[NUM_LAUNCH_CTX];
+  unsigned nextCtx = 0;
+  std::mutex ctxMutex;
+  void* countersDev = nullptr; // wave log of the instrumented twin (one counted batch at a time)
   int numCUs = 256;
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
   uint32_t tuneChunk = 128, tuneLeafBatch = 24, tuneBlocksPerCU = 0; // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU)
@@ -63,7 +75,7 @@ struct Device : RefCounted
   RTCError takeError();
   void useDevice() const; // hipSetDevice(gpu) for the calling thread
   void ensureStaging(size_t bytes);
-  void ensureSpill(size_t bytes);
+  LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded); // picks the next context, makes `stream` wait for its previous user
   void memoryMonitor(ssize_t bytes, bool post);
 };
 

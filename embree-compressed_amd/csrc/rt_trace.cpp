@@ -40,8 +40,8 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   // worst-case stack: 7 siblings per level plus the entry being expanded
   const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
   p.spillDepth = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
-  dev->ensureSpill((size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u);
-  p.spill = dev->spillDev;
+  Device::LaunchCtx& ctx = dev->acquireLaunchCtx((size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u);
+  p.spill = ctx.spill;
   p.counters = dCounters;
   p.cbvhLevels = s->compressionLevel;
   p.numCUs = (uint32_t)dev->numCUs;
@@ -49,9 +49,10 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   p.leafBatch = dev->tuneLeafBatch;
   p.blocksPerCU = dev->tuneBlocksPerCU;
   p.refillBatch = dev->tuneRefillBatch;
-  p.queues = (uint32_t*)dev->queuesDev;
-  HIP_CHECK(hipMemsetAsync(dev->queuesDev, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, dev->stream));
+  p.queues = (uint32_t*)ctx.queues;
+  HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, dev->stream));
   HIP_CHECK(launch_trace(p, dev->stream));
+  HIP_CHECK(hipEventRecord(ctx.done, dev->stream));
 }
 
 void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx,

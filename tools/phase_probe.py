@@ -30,6 +30,7 @@ for name, cfg, sub in (('cbvh.leaf', 'subdiv_accel=bvh4.compressed.leaf', True),
             name, kind, c['waves'], c['iterations'] / c['waves'], c['leafPhases'] / c['waves'], tot / c['waves'],
             c['cyclesFetch'] / tot, c['cyclesNode'] / tot, c['cyclesLeaf'] / tot, c['cyclesPop'] / tot, c['rays'] / max(c['iterations'], 1)))
         print('   loop occupancy %.3f; wave end times (4 us buckets): %s' % (c['activeLaneIters'] / (64.0 * c['iterations']), ' '.join(str(x) for x in c['waveEndHist'])))
-        print('   longest ray %d iterations; drain (last grab -> wave end): mean %.1f us, max %.1f us' % (c['maxRaySteps'], c['drainTicksSum'] / c['waves'] / 100.0, c['drainTicksMax'] / 100.0))
+        print('   stack spills %d;' % c['stackSpills'], end=' ')
+        print('longest ray %d iterations; drain (last grab -> wave end): mean %.1f us, max %.1f us' % (c['maxRaySteps'], c['drainTicksSum'] / c['waves'] / 100.0, c['drainTicksMax'] / 100.0))
         print('   iterations per wave (buckets of 2): %s' % ' '.join(str(x) for x in c['waveIterHist']))
     sc.release(); dev.release()
