@@ -52,7 +52,9 @@ struct RayState
   // hit
   float ngx, ngy, ngz, u, v;
   uint32_t primID, geomID;
-  bool hit;
+  uint32_t hit; // 0/1.  Per-lane flags live in vector registers on purpose: a `bool` that is live across divergent
+                // branches is kept as a 64-bit lane mask in scalar registers and costs three scalar instructions at
+                // every join of every branch it crosses; the loop had ~100 of those per iteration.
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -64,8 +66,10 @@ template <> struct TravRay<true> // node_intersector1.h:108-129
 {
   float ox, oy, oz;
   float rnx, rny, rnz; // rdir_near; rdir_far = rdir_near*(1+3ulp) is re-derived per node (3 multiplies instead of 3 registers)
-  bool negx, negy, negz;
   float tnear;
+  __device__ __forceinline__ bool negx() const { return !(rnx >= 0.0f); }
+  __device__ __forceinline__ bool negy() const { return !(rny >= 0.0f); }
+  __device__ __forceinline__ bool negz() const { return !(rnz >= 0.0f); }
   __device__ __forceinline__ void init(const RayState& r)
   {
     ox = r.ox; oy = r.oy; oz = r.oz;
@@ -74,7 +78,6 @@ template <> struct TravRay<true> // node_intersector1.h:108-129
     const float zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy;
     const float zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
     rnx = 1.0f / zx; rny = 1.0f / zy; rnz = 1.0f / zz;
-    negx = !(rnx >= 0.0f); negy = !(rny >= 0.0f); negz = !(rnz >= 0.0f);
     tnear = fmaxf(r.tnear, 0.0f);
   }
   __device__ __forceinline__ float nearT(float px, float py, float pz) const
@@ -93,8 +96,10 @@ template <> struct TravRay<false> // node_intersector1.h:33-57, AVX2 form with o
 {
   float rx, ry, rz;    // rdir = rcp_safe(dir)
   float orx, ory, orz; // org*rdir
-  bool negx, negy, negz;
   float tnear;
+  __device__ __forceinline__ bool negx() const { return !(rx >= 0.0f); }
+  __device__ __forceinline__ bool negy() const { return !(ry >= 0.0f); }
+  __device__ __forceinline__ bool negz() const { return !(rz >= 0.0f); }
   __device__ __forceinline__ void init(const RayState& r)
   {
     const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx;
@@ -102,7 +107,6 @@ template <> struct TravRay<false> // node_intersector1.h:33-57, AVX2 form with o
     const float zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
     rx = 1.0f / zx; ry = 1.0f / zy; rz = 1.0f / zz; // reference: rcpps + one Newton step (vec3fa.h:133-168)
     orx = r.ox * rx; ory = r.oy * ry; orz = r.oz * rz;
-    negx = !(rx >= 0.0f); negy = !(ry >= 0.0f); negz = !(rz >= 0.0f);
     tnear = fmaxf(r.tnear, 0.0f);
   }
   __device__ __forceinline__ float nearT(float px, float py, float pz) const

@@ -71,8 +71,10 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   TravRay<ROBUST> tr;
   float travFar = 0.f;
   uint32_t sp = 0, cur = REF_EMPTY, rayIdx = 0;
-  bool active = false, needPop = false;
-  r.hit = false;
+  // lane state bits (vector register, see RayState::hit): ST_ACTIVE = the lane owns a ray, ST_POP = its next event is a pop
+  enum : uint32_t { ST_ACTIVE = 1u, ST_POP = 2u };
+  uint32_t st = 0u;
+  r.hit = 0u;
 
   auto push = [&](uint32_t ref, uint32_t dist, uint32_t slot) {
     if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
@@ -108,7 +110,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   for (;;) {
     if (COUNT) nIter++;
     // ---- refill idle lanes ---------------------------------------------------------------------------
-    const uint64_t idleMask = __ballot(!active);
+    const uint64_t idleMask = __ballot(!(st & ST_ACTIVE));
     // refilling a handful of lanes costs as many instructions as refilling all 64: wait until refillBatch lanes are
     // idle (or until nothing else can run)
     if (idleMask != 0ull && !exhausted && (__popcll(idleMask) >= (int)P.refillBatch || idleMask == ~0ull)) {
@@ -137,11 +139,11 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       }
       if (poolNext != poolEnd) {
         const uint32_t mine = poolNext + lane_rank(idleMask);
-        if (!active && mine < poolEnd) {
+        if (!(st & ST_ACTIVE) && mine < poolEnd) {
           rayIdx = mine;
           const char* rp = (const char*)P.rays + (size_t)rayIdx * P.stride;
           load_ray<VEC>(rp, r);
-          r.hit = false;
+          r.hit = 0u;
           // stream front-end: rays with tnear > tfar are skipped (bvh_intersector_stream_filters.cpp:156);
           // occluded: already-occluded rays return early (bvh_intersector1.cpp:132-134)
           bool ok = r.tnear <= r.tfar;
@@ -152,8 +154,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
             travFar = fmaxf(r.tfar, 0.0f); // tray.tfar
             sp = 0;
             cur = P.accel.root;
-            needPop = false;
-            active = true;
+            st = ST_ACTIVE;
           }
         }
         poolNext = min(poolNext + (uint32_t)__popcll(idleMask), poolEnd);
@@ -161,17 +162,16 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     }
     stamp(tFetch);
     if (COUNT) {
-      laneIters += (unsigned long long)__popcll(__ballot(active));
-      if (active) { raySteps++; maxRaySteps = max(maxRaySteps, raySteps); }
+      laneIters += (unsigned long long)__popcll(__ballot((st & ST_ACTIVE) != 0u));
+      if (st & ST_ACTIVE) { raySteps++; maxRaySteps = max(maxRaySteps, raySteps); }
     }
-    if (__ballot(active) == 0ull) {
+    if (__ballot((st & ST_ACTIVE) != 0u) == 0ull) {
       if (exhausted) break;
       continue;
     }
 
     // ---- inner node step ---------------------------------------------------------------------------------
-    const bool atLeaf = active && !needPop && (cur & REF_LEAF);
-    const bool atNode = active && !needPop && !(cur & REF_LEAF);
+    const bool atNode = st == ST_ACTIVE && !(cur & REF_LEAF);
     if (atNode) {
       if (COUNT) wc.nodes++;
       const uint4* np = (const uint4*)(nodes + cur);
@@ -181,12 +181,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
       const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
       // near / far plane bytes per axis: words .x,.y = lower[0..7], .z,.w = upper[0..7]
-      const uint32_t nx0 = tr.negx ? n3.z : n3.x, nx1 = tr.negx ? n3.w : n3.y;
-      const uint32_t fx0 = tr.negx ? n3.x : n3.z, fx1 = tr.negx ? n3.y : n3.w;
-      const uint32_t ny0 = tr.negy ? n4.z : n4.x, ny1 = tr.negy ? n4.w : n4.y;
-      const uint32_t fy0 = tr.negy ? n4.x : n4.z, fy1 = tr.negy ? n4.y : n4.w;
-      const uint32_t nz0 = tr.negz ? n5.z : n5.x, nz1 = tr.negz ? n5.w : n5.y;
-      const uint32_t fz0 = tr.negz ? n5.x : n5.z, fz1 = tr.negz ? n5.y : n5.w;
+      const bool ngx = tr.negx(), ngy = tr.negy(), ngz = tr.negz();
+      const uint32_t nx0 = ngx ? n3.z : n3.x, nx1 = ngx ? n3.w : n3.y;
+      const uint32_t fx0 = ngx ? n3.x : n3.z, fx1 = ngx ? n3.y : n3.w;
+      const uint32_t ny0 = ngy ? n4.z : n4.x, ny1 = ngy ? n4.w : n4.y;
+      const uint32_t fy0 = ngy ? n4.x : n4.z, fy1 = ngy ? n4.y : n4.w;
+      const uint32_t nz0 = ngz ? n5.z : n5.x, nz1 = ngz ? n5.w : n5.y;
+      const uint32_t fz0 = ngz ? n5.x : n5.z, fz1 = ngz ? n5.y : n5.w;
       const uint32_t cref[8] = {n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
 
       uint32_t dist[8];
@@ -207,7 +208,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         mask |= h ? (1u << k) : 0u;
       }
       const int nhit = __popc(mask);
-      if (nhit == 0) needPop = true;
+      if (nhit == 0) st |= ST_POP;
       else if (nhit == 1) {
         const int k = __ffs(mask) - 1;
         uint32_t c = cref[0];
@@ -267,8 +268,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     stamp(tNode);
     // ---- leaf step: run only when enough lanes wait at a leaf, or when nobody has node work -------------------
     // (lanes whose node step just ended at a leaf count as waiting: they need no extra iteration to get there)
-    const bool atLeafNow = active && !needPop && (cur & REF_LEAF);
-    const bool atNodeNext = active && !needPop && !(cur & REF_LEAF);
+    const bool atLeafNow = st == ST_ACTIVE && (cur & REF_LEAF);
+    const bool atNodeNext = st == ST_ACTIVE && !(cur & REF_LEAF);
     const uint64_t leafMask = __ballot(atLeafNow);
     if (leafMask != 0ull) {
       const bool nodeWork = __ballot(atNodeNext) != 0ull;
@@ -278,18 +279,18 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           if (COUNT) wc.leaves++;
           if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
             r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
-            r.hit = true;
+            r.hit = 1u;
             sp = 0;           // any hit found: terminate this ray
           }
           travFar = OCCLUDED ? travFar : r.tfar; // tray.tfar = ray.tfar (bvh_intersector1.cpp:117)
-          needPop = true;
+          st |= ST_POP;
         }
       }
     }
 
     stamp(tLeaf);
     // ---- pop -------------------------------------------------------------------------------------------------------
-    if (active && needPop) {
+    if (st == (ST_ACTIVE | ST_POP)) {
       bool finished = false;
       for (;;) {
         if (sp == 0) { finished = true; break; }
@@ -302,7 +303,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         cur = e.x;
         break;
       }
-      needPop = false;
+      st = ST_ACTIVE;
       if (finished) {
         if (r.hit) {
           char* rp = (char*)P.rays + (size_t)rayIdx * P.stride;
@@ -310,7 +311,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           if (OCCLUDED) ((float*)rp)[8] = r.tfar;
           else store_hit<VEC>(rp, r, P.instID);
         }
-        active = false;
+        st = 0u;
       }
     }
     stamp(tPop);

@@ -131,7 +131,7 @@ struct GridCellLeaf
       r.ngx = best.ngx; r.ngy = best.ngy; r.ngz = best.ngz;
       r.geomID = __float_as_uint(f[36]);
       r.primID = __float_as_uint(f[37]);
-      r.hit = true;
+      r.hit = 1u;
     }
     return false;
   }
@@ -188,11 +188,10 @@ struct CbvhCtx
   // projected ray (compressed.h:470-508) and its robust TravRay<4,4,true> constants (:522-523)
   float ox, oy, oz, dx, dy, dz;
   float rnx, rny, rnz, rfx, rfy, rfz;
-  bool negx, negy, negz;
   float travFar; // travRay.tfar: fixed for the whole blob
   float tfar;    // local tfar, shrinks with hits
   float near, zFactor;
-  bool special;
+  uint32_t special; // 0/1 in a vector register (see RayState::hit)
   float lox, loy, loz; // lOrg
   float rcp_edges, extent;
 };
@@ -225,7 +224,7 @@ __device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float 
   r.ngx = 1.f; r.ngy = 0.f; r.ngz = 0.f; // dummy normal
   r.geomID = H->geomID;
   r.primID = H->primID;
-  r.hit = true;
+  r.hit = 1u;
   c.tfar = t;
   if (c.special) {
     // flat frame: un-project the local hit point and measure the distance in the rotated world frame (:583-587)
@@ -340,7 +339,7 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz,
       r.v = c.H->uv0y + vv * c.H->uv1y;
       r.geomID = c.H->geomID;
       r.primID = c.H->primID;
-      r.hit = true;
+      r.hit = 1u;
       c.tfar = (r.tfar - c.near) * c.zFactor;
     }
   } else { // voxel, compressed.h:614-654
@@ -389,11 +388,12 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
   const float uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
 
   // intersectNodeRobust (node_intersector1.h:351-368) on the two x columns, two y rows, one z slab
-  const float nX0 = ((c.negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((c.negx ? lx0 : ux0) - c.ox) * c.rfx;
-  const float nX1 = ((c.negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((c.negx ? lx1 : ux1) - c.ox) * c.rfx;
-  const float nY0 = ((c.negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((c.negy ? ly0 : uy0) - c.oy) * c.rfy;
-  const float nY1 = ((c.negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((c.negy ? ly1 : uy1) - c.oy) * c.rfy;
-  const float nZ = ((c.negz ? uz : lz) - c.oz) * c.rnz, fZ = ((c.negz ? lz : uz) - c.oz) * c.rfz;
+  const bool negx = !(c.rnx >= 0.f), negy = !(c.rny >= 0.f), negz = !(c.rnz >= 0.f);
+  const float nX0 = ((negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((negx ? lx0 : ux0) - c.ox) * c.rfx;
+  const float nX1 = ((negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((negx ? lx1 : ux1) - c.ox) * c.rfx;
+  const float nY0 = ((negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((negy ? ly0 : uy0) - c.oy) * c.rfy;
+  const float nY1 = ((negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((negy ? ly1 : uy1) - c.oy) * c.rfy;
+  const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * c.rfz;
   float tN[4], tF[4];
   uint32_t d[4];
   uint32_t mask = 0;
@@ -506,7 +506,7 @@ template <int MODE, int LEVELS> struct CbvhLeaf
     project3(H->proj, c.lox + ldx * near, c.loy + ldy * near, c.loz + ldz * near, c.ox, c.oy, c.oz);
     project3(H->proj, c.lox + ldx * far, c.loy + ldy * far, c.loz + ldz * far, tx, ty, tz);
     c.dx = tx - c.ox; c.dy = ty - c.oy; c.dz = tz - c.oz;
-    c.special = false;
+    c.special = 0u;
     c.zFactor = 0.f;
     const float g_epsilon = 1.0E-4f;
     if (fabsf(c.dx) < g_epsilon && fabsf(c.dy) < g_epsilon && fabsf(c.dz) < g_epsilon) {
@@ -515,7 +515,7 @@ template <int MODE, int LEVELS> struct CbvhLeaf
       c.zFactor = 3.402823466e+38f;
       c.tfar = 3.402823466e+38f;
     } else if (fabsf(c.dz) < g_epsilon) {
-      c.special = true;
+      c.special = 1u;
       const float len2 = madd(c.dx, c.dx, madd(c.dy, c.dy, c.dz * c.dz));
       c.tfar = sqrtf(len2);
       const float rl = 1.0f / sqrtf(len2); // reference: rsqrt + Newton step
@@ -533,7 +533,6 @@ template <int MODE, int LEVELS> struct CbvhLeaf
       const float zx = fabsf(c.dx) < 1e-18f ? 1e-18f : c.dx, zy = fabsf(c.dy) < 1e-18f ? 1e-18f : c.dy, zz = fabsf(c.dz) < 1e-18f ? 1e-18f : c.dz;
       c.rnx = 1.0f / zx; c.rny = 1.0f / zy; c.rnz = 1.0f / zz;
       c.rfx = c.rnx * ulp3; c.rfy = c.rny * ulp3; c.rfz = c.rnz * ulp3;
-      c.negx = !(c.rnx >= 0.f); c.negy = !(c.rny >= 0.f); c.negz = !(c.rnz >= 0.f);
     }
     // root: local frame box xy in [-1,1], z from the leaf data (:517-519)
     cbvh_node<MODE, LEVELS, COUNT>(c, 0u, rootWord, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);

@@ -62,7 +62,7 @@ template <bool PLUECKER> struct TriLeaf
         r.ngx = best.ngx; r.ngy = best.ngy; r.ngz = best.ngz;
         r.u = best.u; r.v = best.v;
         r.primID = bestPrim; r.geomID = bestGeom;
-        r.hit = true;
+        r.hit = 1u;
       }
     }
     return false;
