@@ -65,7 +65,11 @@ struct Device : RefCounted
   void* countersDev = nullptr; // wave log of the instrumented twin (one counted batch at a time)
   int numCUs = 256;
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
-  uint32_t tuneChunk = 128, tuneLeafBatch = 24, tuneBlocksPerCU = 0; // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU)
+  // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU).  Measured on MI355X, 1 M-ray batches:
+  // alone on the chip every setting within chunk 128-256, leaf batch 24-40, 2-3 workgroups per CU is within +-4 %; with
+  // four batches in flight 256 / 32 / 2 is +15-20 % over 128 / 24 / 3 (each kernel leaves the third wave slot of a SIMD
+  // to the other batches, and takes its rays in fewer, larger grabs).
+  uint32_t tuneChunk = 256, tuneLeafBatch = 32, tuneBlocksPerCU = 2;
 
   explicit Device(const char* cfg);
   ~Device() override;

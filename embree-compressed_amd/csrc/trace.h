@@ -30,7 +30,10 @@ struct LaunchParams
 static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)
 static const int TRACE_QUEUE_STRIDE = 32; // u32 words between two work-queue heads (128 B: one L2 line each)
 static const int TRACE_BLOCK = 256;     // 4 wavefronts per workgroup
-static const int TRACE_LDS_STACK = 16;  // stack entries per lane kept in LDS (8 bytes each -> 32 KiB / workgroup)
+#ifndef TRACE_LDS_STACK_ENTRIES
+#define TRACE_LDS_STACK_ENTRIES 16
+#endif
+static const int TRACE_LDS_STACK = TRACE_LDS_STACK_ENTRIES; // stack entries per lane kept in LDS (8 bytes each -> 2 KiB per entry and workgroup)
 
 // Number of workgroups of the persistent grid for `count` rays on a chip with `numCUs` compute units.
 uint32_t trace_grid_blocks(uint32_t count, int numCUs);

@@ -1,14 +1,16 @@
 // The traversal kernel skeleton: persistent wavefronts with dynamic ray fetch and per-lane LDS stacks.
 //
 // MI355X design (not a port of the reference's per-ray CPU loop):
-//  * Persistent grid (5 workgroups of 4 waves per CU).  Rays are pulled from 8 work queues (one per blockIdx%8 label,
-//    i.e. per XCD under round-robin placement; the label is used for speed only) in chunks of 128, so that the
-//    atomic traffic stays far below what one counter word sustains and the batch is balanced dynamically: random
-//    rays differ by more than 10x in traversal cost and a static assignment leaves most SIMDs idle in the tail.
+//  * Persistent grid (2 workgroups of 4 waves per CU by default; the third wave slot of a SIMD is left to other batches
+//    in flight).  Rays are pulled from 64 work queues (heads in separate 128-byte lines; a wave starts at its home
+//    queue and finds the next live one with a single vector load of all heads) in chunks of 256, so that the atomic
+//    traffic stays far below what one counter word sustains (~70 ns per RMW and address) and the batch is balanced
+//    dynamically: random rays differ by more than 10x in traversal cost and a static assignment leaves most SIMDs
+//    idle in the tail.
 //  * A lane whose ray has finished is refilled from the wave's chunk (ballot + mbcnt rank), so finished rays do
 //    not park lanes ("wavefront ballot for active-ray compaction").
 //  * if-if traversal step: every iteration each lane handles ONE event: an inner node, a leaf, or a pop.  Leaves
-//    are expensive and rare, so lanes that reached a leaf wait until LEAF_BATCH lanes want one (or no lane can do
+//    are expensive and rare, so lanes that reached a leaf wait until leafBatch lanes want one (or no lane can do
 //    node work): the leaf code then runs with many lanes active instead of a handful.
 //  * Per-lane traversal stack in LDS, entry-major (stack[entry][lane]: bank = lane, never a conflict, whatever
 //    the depth mix), with an HBM overflow area for pathological depths.
@@ -38,9 +40,9 @@ namespace dev {
 #ifndef TRACE_PHASE_STAMPS
 #define TRACE_PHASE_STAMPS 0
 #endif
-static constexpr uint32_t RAY_CHUNK = 128;  // default rays a wave takes from a queue per atomic (LaunchParams::rayChunk)
+// rays a wave takes from a queue per atomic and lanes that must wait at a leaf before the leaf code runs come from
+// LaunchParams::rayChunk / leafBatch (defaults 256 / 32, Device::tuneChunk / tuneLeafBatch)
 static constexpr uint32_t QUEUE_STRIDE = TRACE_QUEUE_STRIDE; // queue heads live in separate 128-byte lines
-static constexpr int LEAF_BATCH = 20;       // default lanes that must wait at a leaf before the leaf code runs (LaunchParams::leafBatch)
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) // number of set bits of `mask` below this lane
 {
