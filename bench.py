@@ -170,11 +170,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BENCH_REHEARSE_GLOO=1: rehearsal of the N>1 launch on a ONE-GPU box (every rank on cuda:0, gloo for the barrier and
+    # the MAX over ranks).  The numbers of such a run mean nothing; it exists to exercise rank handling end to end.
+    rehearse = os.environ.get("BENCH_REHEARSE_GLOO") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("embree-compressed_amd")
     rtc = pkg.rtc
@@ -219,7 +227,7 @@ def main():
 
     dev, sc, cnt, elapsed, kernel_ms, hits, elapsed1 = measure(args.workload, K, W)
     st = sc.stats()
-    rate, worst = D.whole_job_rate(m * K, elapsed, world, device="cuda")
+    rate, worst = D.whole_job_rate(m * K, elapsed, world, device="cpu" if rehearse else "cuda")
     n_node = cnt["nodeVisits"] / max(cnt["rays"], 1)
     n_prim = cnt["primTests"] / max(cnt["rays"], 1)
     n_inner = cnt["innerVisits"] / max(cnt["rays"], 1)
