@@ -4,6 +4,8 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <unordered_map>
 
@@ -63,6 +65,29 @@ struct Device : RefCounted
   unsigned nextCtx = 0;
   std::mutex ctxMutex;
   void* countersDev = nullptr; // wave log of the instrumented twin (one counted batch at a time)
+
+  // Call combiner for small host-pointer calls (rtcIntersect1 / rtcOccluded1 / short 1M streams from many threads):
+  // whoever finds the device idle becomes the leader and traces everything that is pending - its own call and the
+  // calls that queued up behind the previous launch - as ONE batch; the others sleep until their record is done.
+  struct SmallCall
+  {
+    struct Scene* scene;
+    char* base;
+    uint32_t M;
+    size_t stride;
+    bool occluded;
+    uint32_t instID;
+    bool done = false;
+    RTCError error = RTC_ERROR_NONE;
+    std::string message;
+  };
+  std::mutex combMutex;
+  std::condition_variable combCv;
+  std::vector<SmallCall*> combPending;
+  bool combBusy = false;
+  std::atomic<uint64_t> statLaunches{0};      // traversal kernel launches
+  std::atomic<uint64_t> statCombinedCalls{0}; // calls that went through the combiner
+  std::atomic<uint64_t> statCombinedBatches{0}; // batches the combiner formed out of them
   int numCUs = 256;
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
   // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU).  Measured on MI355X, 1 M-ray batches:

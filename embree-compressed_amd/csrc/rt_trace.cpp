@@ -53,6 +53,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, dev->stream));
   HIP_CHECK(launch_trace(p, dev->stream));
   HIP_CHECK(hipEventRecord(ctx.done, dev->stream));
+  dev->statLaunches++;
 }
 
 void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx,
@@ -128,6 +129,92 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
       c.waveIterHist[std::min<unsigned long long>(w.iterations / 2ull, 63ull)] += 1;
     }
   }
+}
+
+// ---- call combiner (row f2) -----------------------------------------------------------------------------------------
+// The reference answers rtcIntersect1 in ~1 us on the calling core; here a call costs a staging copy, a kernel launch
+// and a synchronisation (~60 us) whatever its size.  Harness threads of an embree application call concurrently
+// (SURVEY.md section 8b "Threading"), so the calls that arrive while a launch is in flight are traced together by the
+// next leader: T calling threads then see ~T rays per launch instead of one.  Results are those of independent calls
+// (a stream is M independent single-ray calls); no timer, no extra thread, no CPU traversal.
+static void combine_process(Device* dev, std::vector<Device::SmallCall*>& batch)
+{
+  // group by (scene, kind, instID); each group becomes one contiguous batch
+  std::vector<char> done(batch.size(), 0);
+  for (size_t i = 0; i < batch.size(); i++) {
+    if (done[i]) continue;
+    Device::SmallCall* a = batch[i];
+    std::vector<Device::SmallCall*> group;
+    size_t total = 0;
+    for (size_t j = i; j < batch.size(); j++) {
+      Device::SmallCall* b = batch[j];
+      if (!done[j] && b->scene == a->scene && b->occluded == a->occluded && b->instID == a->instID) {
+        done[j] = 1;
+        group.push_back(b);
+        total += b->M;
+      }
+    }
+    const uint32_t rec = a->occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
+    try {
+      std::vector<char> tmp(total * rec + 16);
+      char* base = (char*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
+      size_t k = 0;
+      for (Device::SmallCall* c : group)
+        for (uint32_t r = 0; r < c->M; r++, k++) memcpy(base + k * rec, c->base + (size_t)r * c->stride, rec);
+      RTCIntersectContext ctx;
+      memset(&ctx, 0, sizeof(ctx));
+      ctx.instID[0] = a->instID;
+      trace_batch(a->scene, base, (uint32_t)total, rec, a->occluded, &ctx, nullptr);
+      k = 0;
+      for (Device::SmallCall* c : group)
+        for (uint32_t r = 0; r < c->M; r++, k++) {
+          char* dst = c->base + (size_t)r * c->stride;
+          memcpy(dst + 32, base + k * rec + 32, 4);
+          if (!c->occluded) memcpy(dst + 48, base + k * rec + 48, 32);
+        }
+      dev->statCombinedBatches++;
+    } catch (const rtc_error& e) {
+      for (Device::SmallCall* c : group) { c->error = e.code; c->message = e.msg; }
+    } catch (const std::exception& e) {
+      for (Device::SmallCall* c : group) { c->error = RTC_ERROR_UNKNOWN; c->message = e.what(); }
+    }
+  }
+}
+
+void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx)
+{
+  Device* dev = s->device;
+  if (M == 0 || M > COMBINE_MAX_RAYS || (ctx && ctx->filter) || s->modified || (((uintptr_t)rays) & 3) ||
+      byteStride > 0xFFFFFFFFull || is_device_pointer(rays)) {
+    trace_batch(s, rays, M, byteStride, occluded, ctx, nullptr); // large, device-resident, or about to raise its own error
+    return;
+  }
+  Device::SmallCall call;
+  call.scene = s;
+  call.base = (char*)rays;
+  call.M = M;
+  call.stride = byteStride;
+  call.occluded = occluded;
+  call.instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
+  dev->statCombinedCalls++;
+  std::unique_lock<std::mutex> lk(dev->combMutex);
+  dev->combPending.push_back(&call);
+  while (!call.done) {
+    if (!dev->combBusy) { // become the leader for everything that is pending now (own call included)
+      dev->combBusy = true;
+      std::vector<Device::SmallCall*> batch;
+      batch.swap(dev->combPending);
+      lk.unlock();
+      combine_process(dev, batch);
+      lk.lock();
+      for (Device::SmallCall* c : batch) c->done = true;
+      dev->combBusy = false;
+      dev->combCv.notify_all();
+    } else
+      dev->combCv.wait(lk);
+  }
+  lk.unlock();
+  if (call.error != RTC_ERROR_NONE) throw rtc_error(call.error, call.message);
 }
 
 void trace_pointers(Scene* s, void** ptrs, uint32_t M, bool occluded, const RTCIntersectContext* ctx)

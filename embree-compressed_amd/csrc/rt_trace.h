@@ -10,5 +10,9 @@ namespace rtamd {
 void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx,
                  TraceCounters* countersOut);
 void trace_pointers(Scene* s, void** ptrs, uint32_t M, bool occluded, const RTCIntersectContext* ctx);
+// Entry for the rtcIntersect1/1M, rtcOccluded1/1M API calls: small host-pointer calls go through the call combiner
+// (SURVEY.md section 8 row f2), everything else straight to trace_batch.
+void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx);
+static const uint32_t COMBINE_MAX_RAYS = 1024; // host-pointer calls up to this size are combined
 
 } // namespace rtamd

@@ -89,6 +89,9 @@ API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop)
   case RTC_DEVICE_PROPERTY_USER_GEOMETRY_SUPPORTED: return 0;
   case RTC_DEVICE_PROPERTY_TASKING_SYSTEM: return 0; // "internal"
   case RTC_DEVICE_PROPERTY_JOIN_COMMIT_SUPPORTED: return 1;
+  case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES: return (ssize_t)D(h)->statLaunches.load();
+  case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS: return (ssize_t)D(h)->statCombinedCalls.load();
+  case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES: return (ssize_t)D(h)->statCombinedBatches.load();
   default: RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown readable property");
   }
   CATCH_END(D(h))
@@ -452,7 +455,7 @@ API void rtcIntersect1(RTCScene h, struct RTCIntersectContext* ctx, struct RTCRa
 {
   CATCH_BEGIN
   VERIFY(h);
-  trace_batch(S(h), rayhit, 1, sizeof(RTCRayHit), false, ctx, nullptr);
+  trace_call(S(h), rayhit, 1, sizeof(RTCRayHit), false, ctx);
   CATCH_END(devOf(h))
 }
 
@@ -460,7 +463,7 @@ API void rtcIntersect1M(RTCScene h, struct RTCIntersectContext* ctx, struct RTCR
 {
   CATCH_BEGIN
   VERIFY(h);
-  trace_batch(S(h), rayhit, M, byteStride, false, ctx, nullptr);
+  trace_call(S(h), rayhit, M, byteStride, false, ctx);
   CATCH_END(devOf(h))
 }
 
@@ -468,7 +471,7 @@ API void rtcOccluded1(RTCScene h, struct RTCIntersectContext* ctx, struct RTCRay
 {
   CATCH_BEGIN
   VERIFY(h);
-  trace_batch(S(h), ray, 1, sizeof(RTCRay), true, ctx, nullptr);
+  trace_call(S(h), ray, 1, sizeof(RTCRay), true, ctx);
   CATCH_END(devOf(h))
 }
 
@@ -476,7 +479,7 @@ API void rtcOccluded1M(RTCScene h, struct RTCIntersectContext* ctx, struct RTCRa
 {
   CATCH_BEGIN
   VERIFY(h);
-  trace_batch(S(h), ray, M, byteStride, true, ctx, nullptr);
+  trace_call(S(h), ray, M, byteStride, true, ctx);
   CATCH_END(devOf(h))
 }
 

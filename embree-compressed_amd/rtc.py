@@ -58,6 +58,12 @@ class RTCAMDSceneStats(C.Structure):
                 ("maxDepth", C.c_uint), ("reserved", C.c_uint)]
 
 
+# rtcore_amd.h: enum RTCAMDDeviceProperty
+RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES = 240
+RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS = 241
+RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES = 242
+
+
 class RTCAMDTraceCounters(C.Structure):
     _fields_ = [(n, C.c_ulonglong) for n in
                 ("rays", "nodeVisits", "leafVisits", "primTests", "innerVisits", "hits", "stackSpills", "reserved",
@@ -184,6 +190,11 @@ class Device:
 
     def stream(self):
         return self.lib.rtcamdGetDeviceStream(self.handle)
+
+    def get_property(self, prop):
+        v = self.lib.rtcGetDeviceProperty(self.handle, int(prop))
+        self.check("rtcGetDeviceProperty")
+        return int(v)
 
     def set_stream(self, hip_stream):
         self.lib.rtcamdSetDeviceStream(self.handle, hip_stream)

@@ -31,6 +31,18 @@ RTC_API void rtcamdSynchronizeDevice(RTCDevice device);
 /* HIP device ordinal the RTCDevice was created on (config key "gpu="). */
 RTC_API int rtcamdGetDeviceOrdinal(RTCDevice device);
 
+/* Extra readable properties for rtcGetDeviceProperty (cast to enum RTCDeviceProperty; the values lie inside that
+ * enum's range and above every value the reference defines): counters of the call
+ * combiner.  Host-pointer calls of up to 1024 rays (rtcIntersect1, rtcOccluded1, short 1M streams) issued
+ * concurrently by several threads are traced together: the calls that arrive while a launch is in flight form the
+ * next batch.  Results are those of independent calls.  (The reference answers such a call on the calling core.) */
+enum RTCAMDDeviceProperty
+{
+  RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES = 240,     /* traversal kernel launches so far */
+  RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS = 241,     /* API calls that went through the combiner */
+  RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES = 242 /* batches formed out of them */
+};
+
 /* Layout facts of a committed scene's device acceleration structure; sizes in bytes.
  * Replaces what the reference prints with verbose=2 (kernels/bvh/bvh_statistics.cpp). */
 struct RTCAMDSceneStats
@@ -51,7 +63,7 @@ struct RTCAMDSceneStats
 RTC_API void rtcamdGetSceneStats(RTCScene scene, struct RTCAMDSceneStats* stats);
 
 /* Per-batch traversal work counters, produced by an instrumented twin of the intersect kernel (same
- * code path, atomics added).  The batch is traced exactly like rtcIntersect1M does.  Used to price the
+ * code path; every wavefront stores one record, folded on the host).  The batch is traced exactly like rtcIntersect1M does.  Used to price the
  * algorithmic bytes per ray, B = 84 + nodes*nodeBytes + prims*primBytes; the
  * reference's counterpart is the EMBREE_STAT_COUNTERS build (kernels/common/stat.h:21-33). */
 struct RTCAMDTraceCounters

@@ -9,10 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIBDIR = os.path.join(ROOT, "embree-compressed_amd", "lib")
 
 
-def _build(tmp_path):
-    exe = str(tmp_path / "triangle_geometry_min")
-    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200112L", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-           os.path.join(ROOT, "examples", "triangle_geometry_min.c"), "-L" + LIBDIR, "-lembree3", "-lm",
+def _build(tmp_path, name="triangle_geometry_min"):
+    exe = str(tmp_path / name)
+    cmd = ["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200112L", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "examples", name + ".c"), "-L" + LIBDIR, "-lembree3", "-lm", "-lpthread",
            "-Wl,-rpath," + LIBDIR, "-o", exe]
     subprocess.check_call(cmd)
     return exe
@@ -20,6 +20,10 @@ def _build(tmp_path):
 
 def test_header_is_c99_and_example_links(tmp_path):
     _build(tmp_path)
+
+
+def test_small_calls_example_links(tmp_path):
+    _build(tmp_path, "small_calls_mt")
 
 
 def test_cxx_header_compiles(tmp_path):
@@ -38,3 +42,17 @@ def test_triangle_geometry_example_runs(tmp_path):
     out = subprocess.run([exe, "gpu=0"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 mismatches" in out.stdout
+
+
+@pytest.mark.gpu
+def test_concurrent_rtcIntersect1_from_c_threads_is_combined(tmp_path):
+    """Row f2: 48 pthreads x 400 single-ray calls; every answer checked in the program, and the calls must have been
+    traced several per launch (C threads queue up behind the launch in flight; Python threads cannot show this)."""
+    import re
+    exe = _build(tmp_path, "small_calls_mt")
+    out = subprocess.run([exe, "48", "400", "gpu=0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 mismatches" in out.stdout
+    per_launch = float(re.search(r"\(([0-9.]+) calls per launch\)", out.stdout).group(1))
+    print(out.stdout)
+    assert per_launch > 4.0, out.stdout

@@ -1,0 +1,82 @@
+"""Row f2 of SURVEY.md section 8: rtcIntersect1 / rtcOccluded1 / short streams issued concurrently from many host
+threads (the way embree harness threads call, section 8b "Threading") are combined into shared launches and still
+return exactly what independent calls return."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_single_ray_calls_are_combined_and_exact(rtc, po, bomberman):
+    verts, fs, fi = bomberman
+    dev = rtc.Device("tri_accel=bvh8.triangle4v")
+    sc = rtc.Scene(dev)
+    sc.add_triangles(verts, rtc.fan_triangulate(fs, fi))
+    sc.commit()
+    lo, hi = verts.min(0), verts.max(0)
+    T, per = 32, 64
+    src = po.make_random_rays(T * per, lo, hi, seed=77)
+    want = rtc.aligned_rayhits(T * per)
+    want[:] = src
+    sc.intersect1M(want)  # one big batch = the reference answer for M independent calls
+    got = rtc.aligned_rayhits(T * per)
+    got[:] = src
+    occ = rtc.aligned_rays(T * per)
+    for f in occ.dtype.names:
+        occ[f] = src[f]
+    wocc = occ.copy()
+    sc.occluded1M(wocc)
+    launches0 = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES)
+    calls0 = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS)
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(t * per, (t + 1) * per):
+                if i % 8 == 7:  # a short stream now and then
+                    continue
+                sc.intersect1(got[i:i + 1])
+                sc.occluded1(occ[i:i + 1])
+            idx = np.arange(t * per + 7, (t + 1) * per, 8)
+            for i in idx:
+                sc.intersect1M(got[i:i + 1])
+                sc.occluded1M(occ[i:i + 1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[0]
+    assert got.tobytes() == want.tobytes()
+    assert occ.tobytes() == wocc.tobytes()
+    calls = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS) - calls0
+    launches = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES) - launches0
+    assert calls == 2 * T * per
+    # the point of the combiner: fewer launches than calls.  Python threads serialise on the GIL between calls, so only
+    # a few calls are ever pending together here (C harness threads queue up far deeper); intersect and occluded
+    # records of one combined batch are two launches.
+    assert launches < 0.8 * calls, (launches, calls)
+    assert (got["geomID"] != 0xFFFFFFFF).sum() > 0
+    sc.release()
+    dev.release()
+
+
+def test_error_of_a_combined_call_reaches_its_caller(rtc):
+    dev = rtc.Device("")
+    sc = rtc.Scene(dev)
+    v = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    sc.add_triangles(v, np.array([[0, 1, 2]], np.uint32))
+    # not committed: rtcIntersect1 must raise INVALID_OPERATION like scene.cpp:25,54
+    rh = rtc.aligned_rayhits(1)
+    with pytest.raises(rtc.RTCError) as e:
+        sc.intersect1(rh)
+    assert e.value.code == 3
+    sc.commit()
+    sc.intersect1(rh)
+    sc.release()
+    dev.release()
