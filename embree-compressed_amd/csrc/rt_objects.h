@@ -161,6 +161,10 @@ struct Geometry : RefCounted
   // buffer slots, keyed by (type, slot)
   std::map<std::pair<int, unsigned>, BufferView> views;
 
+  // rtcInterpolate on subdivision meshes: refined buffers, built on first use, dropped by rtcCommitGeometry
+  std::shared_ptr<void> interpCache;
+  std::mutex interpMutex;
+
   Geometry(Device* d, RTCGeometryType t);
   ~Geometry() override;
 

@@ -5,6 +5,7 @@
 #include "../../include/embree3/rtcore_amd.h"
 #include "rt_objects.h"
 #include "rt_trace.h"
+#include "subdiv_tess.h"
 
 using namespace rtamd;
 
@@ -168,7 +169,15 @@ API RTCGeometry rtcNewGeometry(RTCDevice h, enum RTCGeometryType type)
 
 API void rtcRetainGeometry(RTCGeometry h) { CATCH_BEGIN VERIFY(h); G(h)->retain(); CATCH_END(devOf(h)) }
 API void rtcReleaseGeometry(RTCGeometry h) { CATCH_BEGIN VERIFY(h); G(h)->release(); CATCH_END(nullptr) }
-API void rtcCommitGeometry(RTCGeometry h) { CATCH_BEGIN VERIFY(h); G(h)->committed = true; CATCH_END(devOf(h)) }
+API void rtcCommitGeometry(RTCGeometry h)
+{
+  CATCH_BEGIN
+  VERIFY(h);
+  G(h)->committed = true;
+  std::lock_guard<std::mutex> g(G(h)->interpMutex);
+  G(h)->interpCache.reset(); // buffers may have changed: rtcInterpolate refines them again on next use
+  CATCH_END(devOf(h))
+}
 API void rtcEnableGeometry(RTCGeometry h) { CATCH_BEGIN VERIFY(h); G(h)->enabled = true; CATCH_END(devOf(h)) }
 API void rtcDisableGeometry(RTCGeometry h) { CATCH_BEGIN VERIFY(h); G(h)->enabled = false; CATCH_END(devOf(h)) }
 
@@ -333,7 +342,10 @@ API void rtcInterpolate(const struct RTCInterpolateArguments* args)
   CATCH_BEGIN
   VERIFY(args);
   VERIFY(args->geometry);
-  unsupported("rtcInterpolate");
+  Geometry* g = G(args->geometry);
+  if (g->type == RTC_GEOMETRY_TYPE_TRIANGLE) interpolate_triangles(g, args);
+  else if (g->type == RTC_GEOMETRY_TYPE_SUBDIVISION) interpolate_subdiv(g, args);
+  else unsupported("rtcInterpolate on this geometry type");
   CATCH_END(args && args->geometry ? devOf(args->geometry) : nullptr)
 }
 
@@ -342,7 +354,37 @@ API void rtcInterpolateN(const struct RTCInterpolateNArguments* args)
   CATCH_BEGIN
   VERIFY(args);
   VERIFY(args->geometry);
-  unsupported("rtcInterpolateN");
+  // Geometry::interpolateN, kernels/common/geometry.cpp:187-262: N independent evaluations, results stored SoA [value][i]
+  if (args->valueCount > 256) RT_THROW(RTC_ERROR_INVALID_OPERATION, "maximally 256 floating point values can be interpolated per vertex");
+  const int* valid = (const int*)args->valid;
+  float P[256], dPdu[256], dPdv[256], ddPdudu[256], ddPdvdv[256], ddPdudv[256];
+  for (unsigned i = 0; i < args->N; i++) {
+    if (valid && !valid[i]) continue;
+    RTCInterpolateArguments a;
+    a.geometry = args->geometry;
+    a.primID = args->primIDs[i];
+    a.u = args->u[i];
+    a.v = args->v[i];
+    a.bufferType = args->bufferType;
+    a.bufferSlot = args->bufferSlot;
+    a.P = args->P ? P : nullptr;
+    a.dPdu = args->dPdu ? dPdu : nullptr;
+    a.dPdv = args->dPdu ? dPdv : nullptr;
+    a.ddPdudu = args->ddPdudu ? ddPdudu : nullptr;
+    a.ddPdvdv = args->ddPdudu ? ddPdvdv : nullptr;
+    a.ddPdudv = args->ddPdudu ? ddPdudv : nullptr;
+    a.valueCount = args->valueCount;
+    rtcInterpolate(&a);
+    for (unsigned j = 0; j < args->valueCount; j++) {
+      if (args->P) args->P[(size_t)j * args->N + i] = P[j];
+      if (args->dPdu) { args->dPdu[(size_t)j * args->N + i] = dPdu[j]; args->dPdv[(size_t)j * args->N + i] = dPdv[j]; }
+      if (args->ddPdudu) {
+        args->ddPdudu[(size_t)j * args->N + i] = ddPdudu[j];
+        args->ddPdvdv[(size_t)j * args->N + i] = ddPdvdv[j];
+        args->ddPdudv[(size_t)j * args->N + i] = ddPdudv[j];
+      }
+    }
+  }
   CATCH_END(args && args->geometry ? devOf(args->geometry) : nullptr)
 }
 

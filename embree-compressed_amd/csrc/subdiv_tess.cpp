@@ -1,4 +1,7 @@
 #include "subdiv_tess.h"
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include <algorithm>
 #include <unordered_map>
@@ -332,7 +335,9 @@ struct NormalEval
 
 } // namespace
 
-void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out)
+// Level 0 of a subdivision geometry: control vertices as they are, one 2x2 grid per valid quad face.
+// A face is valid if it is not a hole, its indices are in range and its vertices are finite (SubdivMesh::valid).
+static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std::vector<unsigned>& facePrim)
 {
   const BufferView* vb = geom->view(RTC_BUFFER_TYPE_VERTEX, 0);
   const BufferView* ib = geom->view(RTC_BUFFER_TYPE_INDEX, 0);
@@ -343,10 +348,8 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
     const BufferView* c = geom->view(t, 0);
     if (c && c->valid() && c->count) RT_THROW(RTC_ERROR_INVALID_OPERATION, "crease buffers are not supported by the MI355X tessellator yet");
   }
-  if (L > 10) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "subdivision level too high");
   const RTCSubdivisionMode mode = geom->subdivMode.empty() ? RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY : geom->subdivMode[0];
 
-  Level cur;
   cur.n = 1;
   cur.P.resize(vb->count);
   for (size_t i = 0; i < vb->count; i++) {
@@ -364,8 +367,6 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
         if (f < hole.size()) hole[f] = 1;
       }
 
-  // faces: quads only; a face is valid if its indices are in range and its vertices finite (SubdivMesh::valid)
-  std::vector<unsigned> facePrim;
   size_t cursor = 0;
   for (size_t f = 0; f < fb->count; f++) {
     const unsigned nv = *(const unsigned*)fb->at(f);
@@ -386,6 +387,15 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
     cur.grid.push_back({q[0], q[1], q[3], q[2]}); // row-major 2x2: (0,0)=v0 (1,0)=v1 (0,1)=v3 (1,1)=v2
     facePrim.push_back((unsigned)f);
   }
+  return mode;
+}
+
+void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out)
+{
+  if (L > 10) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "subdivision level too high");
+  Level cur;
+  std::vector<unsigned> facePrim;
+  const RTCSubdivisionMode mode = build_base_level(geom, cur, facePrim);
   if (cur.grid.empty()) return;
 
   bool first = true;
@@ -457,6 +467,246 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
       args.P_x = pg.x.data(); args.P_y = pg.y.data(); args.P_z = pg.z.data();
       args.N = (unsigned)N;
       geom->displacement(&args);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// rtcInterpolate
+// ---------------------------------------------------------------------------------------------------------------------
+// Triangle meshes: the reference's arithmetic (scene_triangle_mesh.cpp:214-270).
+void interpolate_triangles(const Geometry* geom, const RTCInterpolateArguments* args)
+{
+  const BufferView* src = geom->view(args->bufferType, args->bufferSlot);
+  if (!src || !src->valid()) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: buffer slot is not bound");
+  if (args->primID >= geom->numTriangles()) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: invalid primID");
+  unsigned idx[3];
+  geom->triangle(args->primID, idx);
+  const float u = args->u, v = args->v, w = 1.0f - u - v;
+  for (unsigned i = 0; i < args->valueCount; i++) {
+    const float p0 = ((const float*)src->at(idx[0]))[i], p1 = ((const float*)src->at(idx[1]))[i], p2 = ((const float*)src->at(idx[2]))[i];
+    if (args->P) args->P[i] = fmaf(w, p0, fmaf(u, p1, v * p2));
+    if (args->dPdu) { args->dPdu[i] = p1 - p0; args->dPdv[i] = p2 - p0; }
+    if (args->ddPdudu) { args->ddPdudu[i] = 0.f; args->ddPdvdv[i] = 0.f; args->ddPdudv[i] = 0.f; }
+  }
+}
+
+// Subdivision meshes: Catmull-Clark limit surface of any vertex / vertex-attribute buffer at (primID, u, v).
+// The reference evaluates through patch classification, bicubic B-spline patches, feature-adaptive subdivision and
+// Gregory patches (scene_subdiv_mesh.cpp:757-864, patch_eval.h).  Here the buffer is refined K = 3 times with the
+// tessellator's refiner (per three channels); a sub-face all of whose corners are regular interior vertices is a uniform
+// bicubic B-spline patch over its 4x4 neighbourhood - the exact limit surface with exact derivatives; the remaining
+// sub-faces (touching an extraordinary vertex or the boundary: 1/64 of a face per such corner) are evaluated bilinearly
+// between the limit points of their corners, where the reference uses its own approximation (Gregory).
+struct InterpChannels
+{
+  Level lvl;              // level-K values of three channels
+  std::vector<D3> limit;  // their limit points
+};
+struct SubdivInterpCache
+{
+  unsigned n = 8; // sub-faces per face side (2^K)
+  std::vector<int> primToFace;
+  std::vector<std::vector<uint32_t>> grid;   // level-K vertex ids per face
+  std::vector<uint32_t> vqStart, vqList;     // vertex -> incident sub-faces (id = face*n*n + j*n + i)
+  std::vector<uint8_t> irregular;            // vertex is on a boundary, pinned, or has valence != 4
+  std::map<std::pair<int, unsigned>, std::vector<InterpChannels>> buffers; // (type, slot) -> channel triples
+  std::mutex mutex;
+};
+static const unsigned INTERP_LEVELS = 3;
+
+static void refine_to_interp_level(Level& cur, RTCSubdivisionMode mode, std::vector<D3>* limit, std::vector<uint8_t>* irregular)
+{
+  bool first = true;
+  for (unsigned l = 0; l < INTERP_LEVELS; l++) {
+    Refiner r(cur, mode, first);
+    r.accumulate();
+    Level next;
+    r.refine(next);
+    cur = std::move(next);
+    first = false;
+  }
+  Refiner fin(cur, mode, first);
+  fin.accumulate();
+  std::vector<uint8_t> pinned = cur.pinned, bpin = cur.bpin;
+  fin.classify(pinned, bpin);
+  if (limit) {
+    limit->resize(cur.P.size());
+    for (uint32_t v = 0; v < cur.P.size(); v++) (*limit)[v] = fin.limit_point(v, pinned);
+  }
+  if (irregular) {
+    irregular->resize(cur.P.size());
+    for (size_t v = 0; v < cur.P.size(); v++) (*irregular)[v] = (fin.acc[v].nb != 0 || pinned[v] || fin.acc[v].nf != 4 || fin.acc[v].ne != 4) ? 1 : 0;
+  }
+}
+
+static void cubic_bspline(double s, double B[4], double dB[4], double ddB[4])
+{
+  const double s2 = s * s, s3 = s2 * s, r = 1.0 - s;
+  B[0] = r * r * r / 6.0; B[1] = (3.0 * s3 - 6.0 * s2 + 4.0) / 6.0; B[2] = (-3.0 * s3 + 3.0 * s2 + 3.0 * s + 1.0) / 6.0; B[3] = s3 / 6.0;
+  dB[0] = -0.5 * r * r; dB[1] = 1.5 * s2 - 2.0 * s; dB[2] = -1.5 * s2 + s + 0.5; dB[3] = 0.5 * s2;
+  ddB[0] = r; ddB[1] = 3.0 * s - 2.0; ddB[2] = -3.0 * s + 1.0; ddB[3] = s;
+}
+
+void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
+{
+  if (args->bufferType != RTC_BUFFER_TYPE_VERTEX && args->bufferType != RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE)
+    RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: invalid buffer type");
+  const BufferView* src = geom->view(args->bufferType, args->bufferSlot);
+  if (!src || !src->valid()) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: buffer slot is not bound");
+  if (args->valueCount > 256) RT_THROW(RTC_ERROR_INVALID_OPERATION, "maximally 256 floating point values can be interpolated per vertex");
+
+  std::shared_ptr<SubdivInterpCache> cache;
+  {
+    std::lock_guard<std::mutex> g(geom->interpMutex);
+    cache = std::static_pointer_cast<SubdivInterpCache>(geom->interpCache);
+    if (!cache) { // topology part, once per commit of the geometry
+      cache = std::make_shared<SubdivInterpCache>();
+      Level cur;
+      std::vector<unsigned> facePrim;
+      const RTCSubdivisionMode mode = build_base_level(geom, cur, facePrim);
+      const BufferView* fb = geom->view(RTC_BUFFER_TYPE_FACE, 0);
+      cache->primToFace.assign(fb->count, -1);
+      for (size_t f = 0; f < facePrim.size(); f++) cache->primToFace[facePrim[f]] = (int)f;
+      refine_to_interp_level(cur, mode, nullptr, &cache->irregular);
+      cache->n = cur.n;
+      cache->grid = cur.grid;
+      const unsigned n = cur.n, w = n + 1;
+      std::vector<uint32_t> deg(cur.P.size() + 1, 0);
+      for (size_t f = 0; f < cur.grid.size(); f++)
+        for (unsigned j = 0; j < n; j++)
+          for (unsigned i = 0; i < n; i++)
+            for (uint32_t v : {cur.grid[f][j * w + i], cur.grid[f][j * w + i + 1], cur.grid[f][(j + 1) * w + i + 1], cur.grid[f][(j + 1) * w + i]}) deg[v + 1]++;
+      for (size_t v = 0; v < cur.P.size(); v++) deg[v + 1] += deg[v];
+      cache->vqStart = deg;
+      cache->vqList.resize(deg.back());
+      std::vector<uint32_t> fill(deg.begin(), deg.end() - 1);
+      for (size_t f = 0; f < cur.grid.size(); f++)
+        for (unsigned j = 0; j < n; j++)
+          for (unsigned i = 0; i < n; i++) {
+            const uint32_t q = (uint32_t)(f * n * n + (size_t)j * n + i);
+            for (uint32_t v : {cur.grid[f][j * w + i], cur.grid[f][j * w + i + 1], cur.grid[f][(j + 1) * w + i + 1], cur.grid[f][(j + 1) * w + i]}) cache->vqList[fill[v]++] = q;
+          }
+      geom->interpCache = cache;
+    }
+  }
+  const unsigned groups = (args->valueCount + 2) / 3;
+  const std::vector<InterpChannels>* chans = nullptr;
+  {
+    std::lock_guard<std::mutex> g(cache->mutex);
+    std::vector<InterpChannels>& c = cache->buffers[std::make_pair((int)args->bufferType, args->bufferSlot)];
+    if (c.size() < groups) { // refine the channels not seen before
+      Level base;
+      std::vector<unsigned> facePrim;
+      const RTCSubdivisionMode mode = build_base_level(geom, base, facePrim);
+      const size_t floatsPerVertex = src->stride / sizeof(float);
+      for (unsigned gi = (unsigned)c.size(); gi < groups; gi++) {
+        InterpChannels ch;
+        ch.lvl = base;
+        for (size_t v = 0; v < base.P.size() && v < src->count; v++) {
+          const float* p = (const float*)src->at(v);
+          double val[3] = {0.0, 0.0, 0.0};
+          for (unsigned k = 0; k < 3; k++)
+            if (3 * gi + k < args->valueCount && 3 * gi + k < floatsPerVertex) val[k] = p[3 * gi + k];
+          ch.lvl.P[v] = D3(val[0], val[1], val[2]);
+        }
+        refine_to_interp_level(ch.lvl, mode, &ch.limit, nullptr);
+        c.push_back(std::move(ch));
+      }
+    }
+    chans = &c;
+  }
+
+  if (args->primID >= cache->primToFace.size() || cache->primToFace[args->primID] < 0)
+    RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: invalid primID");
+  const size_t f = (size_t)cache->primToFace[args->primID];
+  const unsigned n = cache->n, w = n + 1;
+  const std::vector<uint32_t>& g = cache->grid[f];
+  const double x = (double)args->u * n, y = (double)args->v * n;
+  const unsigned i = (unsigned)std::min<double>(std::max(0.0, floor(x)), n - 1), j = (unsigned)std::min<double>(std::max(0.0, floor(y)), n - 1);
+  const double s = x - i, t = y - j;
+  const uint32_t q = (uint32_t)(f * n * n + (size_t)j * n + i);
+  const uint32_t c00 = g[j * w + i], c10 = g[j * w + i + 1], c11 = g[(j + 1) * w + i + 1], c01 = g[(j + 1) * w + i];
+
+  auto quad_verts = [&](uint32_t qq, uint32_t out[4]) {
+    const size_t ff = qq / (n * n), r = qq % (n * n), jj = r / n, ii = r % n;
+    const std::vector<uint32_t>& gg = cache->grid[ff];
+    out[0] = gg[jj * w + ii]; out[1] = gg[jj * w + ii + 1]; out[2] = gg[(jj + 1) * w + ii + 1]; out[3] = gg[(jj + 1) * w + ii];
+  };
+  // the sub-face other than `self` that contains both a and b; oa / ob = its vertices next to a / b
+  auto across = [&](uint32_t self, uint32_t a, uint32_t b, uint32_t& oa, uint32_t& ob) -> int64_t {
+    for (uint32_t k = cache->vqStart[a]; k < cache->vqStart[a + 1]; k++) {
+      const uint32_t qq = cache->vqList[k];
+      if (qq == self) continue;
+      uint32_t vv[4];
+      quad_verts(qq, vv);
+      int ia = -1, ib = -1;
+      for (int m = 0; m < 4; m++) { if (vv[m] == a) ia = m; if (vv[m] == b) ib = m; }
+      if (ia < 0 || ib < 0) continue;
+      if ((ia + 1) % 4 == ib) { oa = vv[(ia + 3) % 4]; ob = vv[(ib + 1) % 4]; }
+      else if ((ib + 1) % 4 == ia) { oa = vv[(ia + 1) % 4]; ob = vv[(ib + 3) % 4]; }
+      else continue;
+      return qq;
+    }
+    return -1;
+  };
+  // the fourth sub-face around the regular vertex a (not self, not n1, not n2): its vertex opposite a
+  auto diagonal = [&](uint32_t a, uint32_t self, int64_t n1, int64_t n2, uint32_t& od) -> bool {
+    for (uint32_t k = cache->vqStart[a]; k < cache->vqStart[a + 1]; k++) {
+      const uint32_t qq = cache->vqList[k];
+      if (qq == self || (int64_t)qq == n1 || (int64_t)qq == n2) continue;
+      uint32_t vv[4];
+      quad_verts(qq, vv);
+      for (int m = 0; m < 4; m++)
+        if (vv[m] == a) { od = vv[(m + 2) % 4]; return true; }
+    }
+    return false;
+  };
+
+  uint32_t C[4][4];
+  bool regular = !cache->irregular[c00] && !cache->irregular[c10] && !cache->irregular[c11] && !cache->irregular[c01];
+  if (regular) {
+    C[1][1] = c00; C[1][2] = c10; C[2][2] = c11; C[2][1] = c01;
+    const int64_t qb = across(q, c00, c10, C[0][1], C[0][2]);
+    const int64_t qr = across(q, c10, c11, C[1][3], C[2][3]);
+    const int64_t qt = across(q, c11, c01, C[3][2], C[3][1]);
+    const int64_t ql = across(q, c01, c00, C[2][0], C[1][0]);
+    regular = qb >= 0 && qr >= 0 && qt >= 0 && ql >= 0 && diagonal(c00, q, qb, ql, C[0][0]) && diagonal(c10, q, qb, qr, C[0][3]) &&
+              diagonal(c11, q, qr, qt, C[3][3]) && diagonal(c01, q, qt, ql, C[3][0]);
+  }
+  double Bu[4], dBu[4], ddBu[4], Bv[4], dBv[4], ddBv[4];
+  if (regular) { cubic_bspline(s, Bu, dBu, ddBu); cubic_bspline(t, Bv, dBv, ddBv); }
+  const double sc = (double)n;
+  for (unsigned gi = 0; gi < groups; gi++) {
+    const InterpChannels& ch = (*chans)[gi];
+    D3 P, Pu, Pv, Puu, Pvv, Puv;
+    if (regular) {
+      for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+          const D3& cp = ch.lvl.P[C[r][c]];
+          P += cp * (Bv[r] * Bu[c]);
+          Pu += cp * (Bv[r] * dBu[c]);
+          Pv += cp * (dBv[r] * Bu[c]);
+          Puu += cp * (Bv[r] * ddBu[c]);
+          Pvv += cp * (ddBv[r] * Bu[c]);
+          Puv += cp * (dBv[r] * dBu[c]);
+        }
+    } else {
+      const D3 &L00 = ch.limit[c00], &L10 = ch.limit[c10], &L11 = ch.limit[c11], &L01 = ch.limit[c01];
+      P = L00 * ((1 - s) * (1 - t)) + L10 * (s * (1 - t)) + L01 * ((1 - s) * t) + L11 * (s * t);
+      Pu = (L10 - L00) * (1 - t) + (L11 - L01) * t;
+      Pv = (L01 - L00) * (1 - s) + (L11 - L10) * s;
+      Puv = (L11 - L10) - (L01 - L00);
+    }
+    const double vP[3] = {P.x, P.y, P.z}, vu[3] = {Pu.x * sc, Pu.y * sc, Pu.z * sc}, vv[3] = {Pv.x * sc, Pv.y * sc, Pv.z * sc};
+    const double vuu[3] = {Puu.x * sc * sc, Puu.y * sc * sc, Puu.z * sc * sc}, vvv[3] = {Pvv.x * sc * sc, Pvv.y * sc * sc, Pvv.z * sc * sc};
+    const double vuv[3] = {Puv.x * sc * sc, Puv.y * sc * sc, Puv.z * sc * sc};
+    for (unsigned k = 0; k < 3 && 3 * gi + k < args->valueCount; k++) {
+      const unsigned o = 3 * gi + k;
+      if (args->P) args->P[o] = (float)vP[k];
+      if (args->dPdu) { args->dPdu[o] = (float)vu[k]; args->dPdv[o] = (float)vv[k]; }
+      if (args->ddPdudu) { args->ddPdudu[o] = (float)vuu[k]; args->ddPdvdv[o] = (float)vvv[k]; args->ddPdudv[o] = (float)vuv[k]; }
     }
   }
 }

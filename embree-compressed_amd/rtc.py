@@ -20,6 +20,7 @@ RTC_GEOMETRY_TYPE_QUAD = 1
 RTC_GEOMETRY_TYPE_SUBDIVISION = 8
 RTC_BUFFER_TYPE_INDEX = 0
 RTC_BUFFER_TYPE_VERTEX = 1
+RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE = 2
 RTC_BUFFER_TYPE_FACE = 16
 RTC_BUFFER_TYPE_LEVEL = 17
 RTC_FORMAT_UINT = 0x5001
@@ -56,6 +57,21 @@ class RTCAMDSceneStats(C.Structure):
                 ("nodeCount", C.c_size_t), ("nodeBytes", C.c_size_t), ("primCount", C.c_size_t),
                 ("primBytes", C.c_size_t), ("leafCount", C.c_size_t), ("totalBytes", C.c_size_t),
                 ("maxDepth", C.c_uint), ("reserved", C.c_uint)]
+
+
+class RTCInterpolateArguments(C.Structure):
+    _fields_ = [("geometry", C.c_void_p), ("primID", C.c_uint), ("u", C.c_float), ("v", C.c_float), ("bufferType", C.c_int),
+                ("bufferSlot", C.c_uint), ("P", C.POINTER(C.c_float)), ("dPdu", C.POINTER(C.c_float)), ("dPdv", C.POINTER(C.c_float)),
+                ("ddPdudu", C.POINTER(C.c_float)), ("ddPdvdv", C.POINTER(C.c_float)), ("ddPdudv", C.POINTER(C.c_float)),
+                ("valueCount", C.c_uint)]
+
+
+class RTCInterpolateNArguments(C.Structure):
+    _fields_ = [("geometry", C.c_void_p), ("valid", C.c_void_p), ("primIDs", C.POINTER(C.c_uint)), ("u", C.POINTER(C.c_float)),
+                ("v", C.POINTER(C.c_float)), ("N", C.c_uint), ("bufferType", C.c_int), ("bufferSlot", C.c_uint),
+                ("P", C.POINTER(C.c_float)), ("dPdu", C.POINTER(C.c_float)), ("dPdv", C.POINTER(C.c_float)),
+                ("ddPdudu", C.POINTER(C.c_float)), ("ddPdvdv", C.POINTER(C.c_float)), ("ddPdudv", C.POINTER(C.c_float)),
+                ("valueCount", C.c_uint)]
 
 
 # rtcore_amd.h: enum RTCAMDDeviceProperty
@@ -117,6 +133,9 @@ def load_library(path=LIB_PATH):
         "rtcAttachGeometryByID": (None, [vp, vp, u]),
         "rtcDetachGeometry": (None, [vp, u]),
         "rtcGetGeometry": (vp, [vp, u]),
+        "rtcSetGeometryVertexAttributeCount": (None, [vp, u]),
+        "rtcInterpolate": (None, [C.POINTER(RTCInterpolateArguments)]),
+        "rtcInterpolateN": (None, [C.POINTER(RTCInterpolateNArguments)]),
         "rtcSetSceneLevels": (None, [vp, u, u]),
         "rtcSetSceneFlags": (None, [vp, C.c_int]),
         "rtcGetSceneFlags": (C.c_int, [vp]),
@@ -278,6 +297,57 @@ class Scene:
         self._keep += [vpad, fs, fi, lv]
         self.device.check("add_subdiv")
         return gid
+
+    def set_vertex_attribute(self, geom_id, slot, values):
+        """Bind a float32 [nv, k] (k <= 4) array as vertex attribute `slot` of an attached geometry and re-commit it."""
+        L = self.lib
+        a = np.ascontiguousarray(values, dtype=np.float32)
+        pad = np.zeros((a.shape[0] + 2, a.shape[1]), dtype=np.float32)
+        pad[: a.shape[0]] = a
+        g = L.rtcGetGeometry(self.handle, geom_id)
+        L.rtcSetGeometryVertexAttributeCount(g, slot + 1)
+        fmt = {1: RTC_FORMAT_FLOAT, 2: RTC_FORMAT_FLOAT + 1, 3: RTC_FORMAT_FLOAT3, 4: RTC_FORMAT_FLOAT3 + 1}[a.shape[1]]
+        L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot, fmt, pad.ctypes.data, 0, 4 * a.shape[1], a.shape[0])
+        L.rtcCommitGeometry(g)
+        self._keep.append(pad)
+        self.device.check("set_vertex_attribute")
+
+    def interpolate(self, geom_id, prim_id, u, v, buffer_type=None, slot=0, count=3, derivs=2):
+        """rtcInterpolate: returns (P, dPdu, dPdv, ddPdudu, ddPdvdv, ddPdudv) as float32 arrays (None beyond `derivs`)."""
+        bt = RTC_BUFFER_TYPE_VERTEX if buffer_type is None else buffer_type
+        out = [np.zeros(count, np.float32) for _ in range(6)]
+        a = RTCInterpolateArguments()
+        a.geometry = self.lib.rtcGetGeometry(self.handle, geom_id)
+        a.primID, a.u, a.v, a.bufferType, a.bufferSlot, a.valueCount = prim_id, u, v, bt, slot, count
+        fp = C.POINTER(C.c_float)
+        a.P = out[0].ctypes.data_as(fp)
+        if derivs >= 1:
+            a.dPdu, a.dPdv = out[1].ctypes.data_as(fp), out[2].ctypes.data_as(fp)
+        if derivs >= 2:
+            a.ddPdudu, a.ddPdvdv, a.ddPdudv = out[3].ctypes.data_as(fp), out[4].ctypes.data_as(fp), out[5].ctypes.data_as(fp)
+        self.lib.rtcInterpolate(C.byref(a))
+        self.device.check("rtcInterpolate")
+        return tuple(o if k == 0 or (k <= 2 and derivs >= 1) or derivs >= 2 else None for k, o in enumerate(out))
+
+    def interpolateN(self, geom_id, prim_ids, u, v, buffer_type=None, slot=0, count=3, valid=None):
+        """rtcInterpolateN: returns P [count, N] and dPdu, dPdv (SoA like the reference)."""
+        bt = RTC_BUFFER_TYPE_VERTEX if buffer_type is None else buffer_type
+        pid = np.ascontiguousarray(prim_ids, np.uint32)
+        uu, vv = np.ascontiguousarray(u, np.float32), np.ascontiguousarray(v, np.float32)
+        n = pid.shape[0]
+        P, du, dv = (np.zeros((count, n), np.float32) for _ in range(3))
+        a = RTCInterpolateNArguments()
+        a.geometry = self.lib.rtcGetGeometry(self.handle, geom_id)
+        fp = C.POINTER(C.c_float)
+        a.primIDs, a.u, a.v, a.N = pid.ctypes.data_as(C.POINTER(C.c_uint)), uu.ctypes.data_as(fp), vv.ctypes.data_as(fp), n
+        if valid is not None:
+            vm = np.ascontiguousarray(valid, np.int32)
+            a.valid = vm.ctypes.data
+        a.bufferType, a.bufferSlot, a.valueCount = bt, slot, count
+        a.P, a.dPdu, a.dPdv = P.ctypes.data_as(fp), du.ctypes.data_as(fp), dv.ctypes.data_as(fp)
+        self.lib.rtcInterpolateN(C.byref(a))
+        self.device.check("rtcInterpolateN")
+        return P, du, dv
 
     def set_levels(self, subdivision_level, compression_level):
         self.lib.rtcSetSceneLevels(self.handle, subdivision_level, compression_level)

@@ -1,0 +1,124 @@
+"""rtcInterpolate / rtcInterpolateN on a `gpu=none` device.
+
+Triangle meshes follow scene_triangle_mesh.cpp:214-270 exactly.  Subdivision meshes are checked against an independent
+numpy evaluation of the uniform bicubic B-spline surface of the CONTROL mesh (what the limit surface of a regular region
+is), against the tessellator's limit grid at dyadic parameters, and for the internal consistency of the derivatives."""
+import numpy as np
+import pytest
+
+
+def _bspline(s):
+    r = 1 - s
+    B = np.array([r ** 3 / 6, (3 * s ** 3 - 6 * s ** 2 + 4) / 6, (-3 * s ** 3 + 3 * s ** 2 + 3 * s + 1) / 6, s ** 3 / 6])
+    dB = np.array([-0.5 * r * r, 1.5 * s * s - 2 * s, -1.5 * s * s + s + 0.5, 0.5 * s * s])
+    ddB = np.array([r, 3 * s - 2, -3 * s + 1, s])
+    return B, dB, ddB
+
+
+def _torus(nu=8, nv=6):
+    """closed all-regular quad mesh (every vertex has valence 4)"""
+    verts = np.zeros((nu * nv, 3), np.float32)
+    for j in range(nv):
+        for i in range(nu):
+            a, b = 2 * np.pi * i / nu, 2 * np.pi * j / nv
+            verts[j * nu + i] = [(3 + np.cos(b) * (1 + 0.2 * np.sin(3 * a))) * np.cos(a), (3 + np.cos(b)) * np.sin(a), np.sin(b) + 0.1 * np.cos(2 * a)]
+    faces = [(j * nu + i, j * nu + (i + 1) % nu, ((j + 1) % nv) * nu + (i + 1) % nu, ((j + 1) % nv) * nu + i) for j in range(nv) for i in range(nu)]
+    return verts, np.array(faces, np.uint32), nu, nv
+
+
+def test_triangle_interpolation_matches_the_reference_formula(rtc):
+    dev = rtc.Device("gpu=none")
+    sc = rtc.Scene(dev)
+    rng = np.random.RandomState(3)
+    v = rng.rand(5, 3).astype(np.float32)
+    t = np.array([[0, 1, 2], [2, 3, 4]], np.uint32)
+    gid = sc.add_triangles(v, t)
+    col = rng.rand(5, 4).astype(np.float32)
+    sc.set_vertex_attribute(gid, 0, col)
+    sc.commit()
+    for prim in (0, 1):
+        for u, w in ((0.25, 0.5), (0.0, 0.0), (1.0, 0.0), (0.1, 0.9)):
+            P, du, dv, duu, dvv, duv = sc.interpolate(gid, prim, u, w)
+            p0, p1, p2 = v[t[prim]]
+            ww = np.float32(1.0) - np.float32(u) - np.float32(w)
+            want = np.array([np.float32(np.float64(ww) * p0[k] + (np.float64(np.float32(u)) * p1[k] + np.float64(np.float32(np.float32(w) * p2[k])))) for k in range(3)], np.float32)
+            assert np.allclose(P, want, rtol=0, atol=1e-6)
+            assert np.array_equal(du, p1 - p0) and np.array_equal(dv, p2 - p0)
+            assert not duu.any() and not dvv.any() and not duv.any()
+            C4 = sc.interpolate(gid, prim, u, w, buffer_type=rtc.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot=0, count=4, derivs=1)
+            c0, c1, c2 = col[t[prim]]
+            assert np.allclose(C4[0], ww * c0 + np.float32(u) * c1 + np.float32(w) * c2, atol=1e-6)
+            assert np.array_equal(C4[1], c1 - c0)
+    Pn, dun, dvn = sc.interpolateN(gid, [0, 1, 1], [0.2, 0.3, 0.4], [0.1, 0.2, 0.3], valid=[-1, 0, -1])
+    assert Pn.shape == (3, 3) and not Pn[:, 1].any()  # masked-out entry untouched, SoA [value][i] layout
+    assert np.allclose(Pn[:, 2], sc.interpolate(gid, 1, 0.4, 0.3)[0])
+    sc.release()
+    dev.release()
+
+
+def test_subdiv_interpolation_is_the_bicubic_bspline_surface_on_a_regular_mesh(rtc):
+    verts, faces, nu, nv = _torus()
+    dev = rtc.Device("gpu=none")
+    sc = rtc.Scene(dev)
+    gid = sc.add_subdiv(verts, np.full(len(faces), 4, np.uint32), faces.ravel())
+    sc.commit()
+    V = verts.astype(np.float64).reshape(nv, nu, 3)
+    rng = np.random.RandomState(5)
+    worst = 0.0
+    for _ in range(200):
+        f = rng.randint(len(faces))
+        u, v = rng.rand(2)
+        if rng.rand() < 0.2:
+            u, v = rng.choice([0.0, 1.0, 0.5, 0.125]), rng.choice([0.0, 1.0, 0.375])
+        fj, fi = divmod(f, nu)
+        Bu, dBu, ddBu = _bspline(u)
+        Bv, dBv, ddBv = _bspline(v)
+        ctl = np.array([[V[(fj - 1 + r) % nv, (fi - 1 + c) % nu] for c in range(4)] for r in range(4)])  # [r][c][xyz]
+        want = [np.einsum("r,c,rck->k", a, b, ctl) for a, b in ((Bv, Bu), (Bv, dBu), (dBv, Bu), (Bv, ddBu), (ddBv, Bu), (dBv, dBu))]
+        got = sc.interpolate(gid, f, float(u), float(v))
+        for g, w, tol in zip(got, want, (2e-6, 1e-5, 1e-5, 1e-4, 1e-4, 1e-4)):
+            err = np.abs(g - w).max() / max(1.0, np.abs(w).max())
+            worst = max(worst, err)
+            assert err < tol, (f, u, v, g, w)
+    assert worst > 0  # float32 outputs of a double evaluation
+    sc.release()
+    dev.release()
+
+
+def test_subdiv_interpolation_agrees_with_the_tessellator_and_itself(rtc, bomberman):
+    """bomberman has extraordinary vertices and boundaries: at the dyadic parameters of level 3 every face must give the
+    tessellator's limit point (both evaluation branches are exact there); derivatives agree with central differences in
+    regular regions; a copy of the vertex buffer bound as attribute interpolates identically."""
+    verts, fs, fi = bomberman
+    dev = rtc.Device("gpu=none,keep_grids=1")
+    sc = rtc.Scene(dev)
+    gid = sc.add_subdiv(verts, fs, fi)
+    sc.set_vertex_attribute(gid, 1, np.concatenate([verts, verts[:, :1] * 2], 1))
+    sc.set_levels(3, 2)
+    sc.commit()
+    raw = sc.accel_data(4)
+    w = 9
+    per = 12 + 12 * w * w
+    grids = {int(raw[p * per: p * per + 12].view(np.uint32)[1]): raw[p * per + 12: (p + 1) * per].view(np.float32).reshape(3, w, w)
+             for p in range(len(raw) // per)}
+    scale = np.abs(verts).max()
+    rng = np.random.RandomState(9)
+    for prim in rng.choice(sorted(grids), 60, replace=False):
+        g = grids[int(prim)]
+        for (i, j) in ((0, 0), (8, 8), (3, 5), (8, 0), (4, 4), (1, 7)):
+            P = sc.interpolate(gid, int(prim), i / 8.0, j / 8.0, derivs=0)[0]
+            assert np.abs(P - g[:, j, i]).max() < 2e-6 * scale, (prim, i, j)
+        u, v = 0.3 + 0.4 * rng.rand(2)
+        P, du, dv, duu, dvv, duv = sc.interpolate(gid, int(prim), u, v)
+        A = sc.interpolate(gid, int(prim), u, v, buffer_type=rtc.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot=1, count=4, derivs=1)
+        assert np.allclose(A[0][:3], P, atol=1e-6 * scale) and abs(A[0][3] - 2 * P[0]) < 1e-5 * scale
+        assert np.allclose(A[1][:3], du, atol=1e-5 * scale)
+        h = 1e-3
+        fdu = (sc.interpolate(gid, int(prim), u + h, v, derivs=0)[0].astype(np.float64) - sc.interpolate(gid, int(prim), u - h, v, derivs=0)[0]) / (2 * h)
+        fdv = (sc.interpolate(gid, int(prim), u, v + h, derivs=0)[0].astype(np.float64) - sc.interpolate(gid, int(prim), u, v - h, derivs=0)[0]) / (2 * h)
+        tol = 2e-2 * max(np.abs(du).max(), np.abs(dv).max(), 1e-3 * scale)  # float32 positions / 2h
+        assert np.abs(fdu - du).max() < tol and np.abs(fdv - dv).max() < tol, (prim, u, v, fdu, du)
+    with pytest.raises(rtc.RTCError):
+        sc.interpolate(gid, 10 ** 6, 0.5, 0.5)
+    sc.release()
+    dev.release()
