@@ -219,6 +219,9 @@ struct Scene : RefCounted
   RTCProgressMonitorFunction progressFn = nullptr;
   void* progressUser = nullptr;
   bool modified = true; // "scene got not committed" until the first commit (scene.cpp:25,54)
+  // filter callbacks present at commit time (Scene::hasGeometryFilterFunction, scene.h): they route a batch through the
+  // host filter loop of rt_trace.cpp
+  bool triIntersectFilter = false, triOccludedFilter = false, subdivFilter = false;
   std::mutex buildMutex;
   Box3 bounds;
 

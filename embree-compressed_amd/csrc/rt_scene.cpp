@@ -298,6 +298,15 @@ void Scene::commit()
       RT_THROW(RTC_ERROR_INVALID_OPERATION, "geometry type not supported by the MI355X traversal path");
     }
   }
+  triIntersectFilter = triOccludedFilter = subdivFilter = false;
+  for (Geometry* geo : geometries) {
+    if (!geo || !geo->enabled) continue;
+    if (geo->type == RTC_GEOMETRY_TYPE_TRIANGLE) {
+      triIntersectFilter |= geo->intersectFilter != nullptr;
+      triOccludedFilter |= geo->occludedFilter != nullptr;
+    } else
+      subdivFilter |= geo->intersectFilter != nullptr || geo->occludedFilter != nullptr;
+  }
   if (progressFn && !progressFn(progressUser, 0.0)) RT_THROW(RTC_ERROR_CANCELLED, "progress monitor forced termination");
   bounds = Box3();
   build_triangle_accel(this);

@@ -25,7 +25,7 @@ static bool is_device_pointer(const void* p)
 }
 
 static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
-                      WaveRecord* dCounters)
+                      WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr)
 {
   Device* dev = s->device;
   if (A.kind == ACCEL_NONE || A.root == REF_EMPTY) return;
@@ -50,10 +50,153 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   p.blocksPerCU = dev->tuneBlocksPerCU;
   p.refillBatch = dev->tuneRefillBatch;
   p.queues = (uint32_t*)ctx.queues;
+  p.exclOffsets = exclOffsets;
+  p.exclPairs = exclPairs;
   HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, dev->stream));
   HIP_CHECK(launch_trace(p, dev->stream));
   HIP_CHECK(hipEventRecord(ctx.done, dev->stream));
   dev->statLaunches++;
+}
+
+// ---- filter callbacks (row f3) -----------------------------------------------------------------------------------------
+// Filter functions are host function pointers (intersector_epilog.h:251-291, filter.h:27-130): the device cannot call
+// them.  Two-phase scheme: the kernel finds the closest candidate of every ray; the host runs the geometry's filter and
+// then the context filter on it with the reference's argument protocol (ray.tfar = candidate distance, N = 1); an
+// accepted candidate is the ray's result; a rejected one is put on the ray's exclusion list and the ray is traced again
+// (only those rays, compacted), the kernel skipping listed triangles, until every ray has an accepted hit or none.
+// For pure accept/reject filters this is the reference's result: rejected candidates never shorten the ray there either,
+// so the closest accepted candidate wins.  The callbacks see the candidates of a ray in order of distance instead of
+// traversal order, each at most once.  Occlusion filters run the same loop on closest candidates (any accepted candidate
+// = occluded).  Triangle geometry only: a subdivision patch's triangles share one primID, so they cannot be excluded one
+// by one.
+static const unsigned FILTER_MAX_ROUNDS = 256;
+
+static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx)
+{
+  Device* dev = s->device;
+  if (s->subdivFilter || ((ctx && ctx->filter) && s->subdivAccel.kind != ACCEL_NONE && s->subdivAccel.root != REF_EMPTY))
+    RT_THROW(RTC_ERROR_INVALID_OPERATION, "filter functions on subdivision geometry are not supported by the MI355X path");
+  RTCIntersectContext localCtx;
+  if (!ctx) { memset(&localCtx, 0, sizeof(localCtx)); localCtx.instID[0] = RTC_INVALID_GEOMETRY_ID; ctx = &localCtx; }
+  const uint32_t instID = ctx->instID[0];
+  const uint32_t recIn = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
+  std::lock_guard<std::mutex> lock(dev->launchMutex);
+
+  // the caller's records, on the host
+  const bool devPtr = is_device_pointer(rays);
+  const size_t span = (size_t)(M - 1) * byteStride + recIn;
+  std::vector<char> mirror;
+  char* src = (char*)rays;
+  if (devPtr) {
+    mirror.resize(span);
+    HIP_CHECK(hipMemcpyAsync(mirror.data(), rays, span, hipMemcpyDeviceToHost, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    src = mirror.data();
+  }
+  std::vector<RTCRayHit> W(M);
+  std::vector<uint32_t> act;
+  act.reserve(M);
+  for (uint32_t i = 0; i < M; i++) {
+    memcpy(&W[i].ray, src + (size_t)i * byteStride, sizeof(RTCRay));
+    if (occluded) {
+      memset(&W[i].hit, 0, sizeof(RTCHit));
+      W[i].hit.geomID = W[i].hit.primID = W[i].hit.instID[0] = RTC_INVALID_GEOMETRY_ID;
+    } else
+      memcpy(&W[i].hit, src + (size_t)i * byteStride + sizeof(RTCRay), sizeof(RTCHit));
+    if (W[i].ray.tnear <= W[i].ray.tfar && !(occluded && W[i].ray.tfar < 0.0f)) act.push_back(i);
+  }
+  std::vector<std::vector<uint2>> excl(M);
+  std::vector<uint32_t> offsets, next;
+  std::vector<uint2> pairs;
+  void* dExcl = nullptr;
+  size_t dExclBytes = 0;
+  auto freeExcl = [&]() { if (dExcl) hipFree(dExcl); dExcl = nullptr; };
+  try {
+    for (unsigned round = 0; !act.empty() && round < FILTER_MAX_ROUNDS; round++) {
+      const uint32_t K = (uint32_t)act.size();
+      const size_t bytes = (size_t)K * sizeof(RTCRayHit);
+      dev->ensureStaging(bytes);
+      RTCRayHit* h = (RTCRayHit*)dev->stageHost;
+      offsets.assign(K + 1, 0);
+      pairs.clear();
+      for (uint32_t k = 0; k < K; k++) {
+        h[k] = W[act[k]];
+        offsets[k] = (uint32_t)pairs.size();
+        pairs.insert(pairs.end(), excl[act[k]].begin(), excl[act[k]].end());
+      }
+      offsets[K] = (uint32_t)pairs.size();
+      const uint32_t* dOff = nullptr;
+      const uint2* dPairs = nullptr;
+      if (!pairs.empty()) {
+        const size_t offBytes = ((size_t)(K + 1) * 4 + 15) & ~(size_t)15, need = offBytes + pairs.size() * sizeof(uint2);
+        if (need > dExclBytes) {
+          HIP_CHECK(hipStreamSynchronize(dev->stream));
+          freeExcl();
+          dExclBytes = need * 2;
+          HIP_CHECK(hipMalloc(&dExcl, dExclBytes));
+        }
+        HIP_CHECK(hipMemcpyAsync(dExcl, offsets.data(), (size_t)(K + 1) * 4, hipMemcpyHostToDevice, dev->stream));
+        HIP_CHECK(hipMemcpyAsync((char*)dExcl + offBytes, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, dev->stream));
+        dOff = (const uint32_t*)dExcl;
+        dPairs = (const uint2*)((char*)dExcl + offBytes);
+      }
+      HIP_CHECK(hipMemcpyAsync(dev->stageDev, h, bytes, hipMemcpyHostToDevice, dev->stream));
+      launch_on(s, s->triAccel, dev->stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr, dOff, dPairs);
+      launch_on(s, s->subdivAccel, dev->stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr);
+      HIP_CHECK(hipMemcpyAsync(h, dev->stageDev, bytes, hipMemcpyDeviceToHost, dev->stream));
+      HIP_CHECK(hipStreamSynchronize(dev->stream));
+      next.clear();
+      for (uint32_t k = 0; k < K; k++) {
+        const uint32_t i = act[k];
+        const RTCRayHit& got = h[k];
+        const bool found = got.hit.geomID != RTC_INVALID_GEOMETRY_ID &&
+                           (got.ray.tfar != W[i].ray.tfar || got.hit.primID != W[i].hit.primID || got.hit.geomID != W[i].hit.geomID);
+        if (!found) continue; // miss: the caller's record stays as it is
+        // the hit reports instID in geomID when instanced; instancing is not on this path, so geomID is the geometry
+        Geometry* geo = got.hit.geomID < s->geometries.size() ? s->geometries[got.hit.geomID] : nullptr;
+        RTCFilterFunctionN fn = geo ? (occluded ? geo->occludedFilter : geo->intersectFilter) : nullptr;
+        bool accepted = true;
+        RTCRayHit cand = W[i];
+        cand.ray.tfar = got.ray.tfar; // filter.h / intersector_epilog.h:277-279: the callback sees tfar = candidate distance
+        RTCHit hit = got.hit;
+        if (fn || ctx->filter) {
+          int mask = -1;
+          RTCFilterFunctionNArguments a;
+          a.valid = &mask;
+          a.geometryUserPtr = geo ? geo->userPtr : nullptr;
+          a.context = ctx;
+          a.ray = (RTCRayN*)&cand.ray;
+          a.hit = (RTCHitN*)&hit;
+          a.N = 1;
+          if (fn) fn(&a);
+          if (mask != 0 && ctx->filter) ctx->filter(&a);
+          accepted = mask != 0;
+        }
+        if (accepted) {
+          if (occluded) W[i].ray.tfar = -std::numeric_limits<float>::infinity();
+          else { W[i].ray = cand.ray; W[i].hit = hit; } // copyHitToRay
+        } else {
+          excl[i].push_back(make_uint2(got.hit.geomID, got.hit.primID));
+          next.push_back(i);
+        }
+      }
+      act.swap(next);
+    }
+  } catch (...) {
+    freeExcl();
+    throw;
+  }
+  freeExcl();
+  // outputs: tfar, and the hit for rtcIntersect
+  for (uint32_t i = 0; i < M; i++) {
+    char* dst = src + (size_t)i * byteStride;
+    memcpy(dst + 32, &W[i].ray.tfar, 4);
+    if (!occluded) memcpy(dst + sizeof(RTCRay), &W[i].hit, sizeof(RTCHit));
+  }
+  if (devPtr) {
+    HIP_CHECK(hipMemcpyAsync(rays, mirror.data(), span, hipMemcpyHostToDevice, dev->stream));
+    HIP_CHECK(hipStreamSynchronize(dev->stream));
+  }
 }
 
 void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx,
@@ -63,9 +206,12 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   if (s->modified) RT_THROW(RTC_ERROR_INVALID_OPERATION, "scene got not committed"); // scene.cpp:25,54
   if (M == 0) return;
   dev->useDevice();
-  if (ctx && ctx->filter) RT_THROW(RTC_ERROR_INVALID_OPERATION, "context filter functions are not run by the device path");
   if (byteStride > 0xFFFFFFFFull) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "byteStride too large");
   if (((uintptr_t)rays) & 3) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "ray not aligned to 4 bytes"); // rtcore.cpp:413
+  if (!countersOut && ((ctx && ctx->filter) || s->subdivFilter || (occluded ? s->triOccludedFilter : s->triIntersectFilter))) {
+    trace_filtered(s, rays, M, byteStride, occluded, ctx);
+    return;
+  }
   const uint32_t instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
   const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
 
@@ -184,7 +330,7 @@ static void combine_process(Device* dev, std::vector<Device::SmallCall*>& batch)
 void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx)
 {
   Device* dev = s->device;
-  if (M == 0 || M > COMBINE_MAX_RAYS || (ctx && ctx->filter) || s->modified || (((uintptr_t)rays) & 3) ||
+  if (M == 0 || M > COMBINE_MAX_RAYS || (ctx && ctx->filter) || s->triIntersectFilter || s->triOccludedFilter || s->subdivFilter || s->modified || (((uintptr_t)rays) & 3) ||
       byteStride > 0xFFFFFFFFull || is_device_pointer(rays)) {
     trace_batch(s, rays, M, byteStride, occluded, ctx, nullptr); // large, device-resident, or about to raise its own error
     return;

@@ -81,7 +81,7 @@ API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop)
   case RTC_DEVICE_PROPERTY_RAY_STREAM_SUPPORTED: return 1;
   case RTC_DEVICE_PROPERTY_RAY_MASK_SUPPORTED: return 0;          // EMBREE_RAY_MASK default OFF (CMakeLists.txt:114)
   case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED: return 0;    // CMakeLists.txt:115
-  case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED: return 0;   // host callbacks are not run by the device path
+  case RTC_DEVICE_PROPERTY_FILTER_FUNCTION_SUPPORTED: return 1;   // host callbacks, two-phase (rt_trace.cpp, triangle geometry)
   case RTC_DEVICE_PROPERTY_IGNORE_INVALID_RAYS_ENABLED: return 0; // CMakeLists.txt:117
   case RTC_DEVICE_PROPERTY_TRIANGLE_GEOMETRY_SUPPORTED: return 1;
   case RTC_DEVICE_PROPERTY_QUAD_GEOMETRY_SUPPORTED: return 0;

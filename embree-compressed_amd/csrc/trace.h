@@ -24,7 +24,12 @@ struct LaunchParams
   uint32_t leafBatch;      // lanes waiting at a leaf before the leaf phase runs (tuning knob, env RTAMD_LEAF_BATCH)
   uint32_t blocksPerCU;    // 0 = occupancy-derived (tuning knob, env RTAMD_BLOCKS_PER_CU)
   uint32_t refillBatch;    // idle lanes needed before a wave fetches new rays (tuning knob, env RTAMD_REFILL_BATCH)
-  uint32_t* queues;        // 8 work-queue heads (one per blockIdx%8 label), zeroed on the stream before the launch
+  uint32_t* queues;        // TRACE_QUEUES work-queue heads, zeroed on the stream before the launch
+  // Filter-function re-trace (row f3): ray i skips the triangles (geomID, primID) listed in
+  // exclPairs[exclOffsets[i] .. exclOffsets[i+1]) - the candidates a host filter callback rejected in earlier rounds.
+  // nullptr for ordinary launches.
+  const uint32_t* exclOffsets;
+  const uint2* exclPairs;
 };
 
 static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)

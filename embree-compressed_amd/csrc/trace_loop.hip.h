@@ -20,7 +20,7 @@
 //
 // A kernel is this skeleton instantiated with a Leaf policy:
 //   struct Leaf { static __device__ void prepare();   // once per workgroup, before the loop (LDS tables)
-//                 template<bool OCCLUDED,bool COUNT> static __device__ bool intersect(const LaunchParams&, uint32_t ref, RayState&, WorkCounters&); }
+//                 template<bool OCCLUDED,bool COUNT> static __device__ bool intersect(const LaunchParams&, uint32_t ref, RayState&, WorkCounters&, uint32_t rayIdx); }
 // intersect returns true when an any-hit query is finished (ray occluded).
 #pragma once
 #include "trace_common.hip.h"
@@ -279,7 +279,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         if (COUNT) nLeafPhase++;
         if (atLeafNow) {
           if (COUNT) wc.leaves++;
-          if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc)) {
+          if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc, rayIdx)) {
             r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
             r.hit = 1u;
             sp = 0;           // any hit found: terminate this ray

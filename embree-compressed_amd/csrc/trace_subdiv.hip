@@ -72,7 +72,7 @@ struct GridCellLeaf
   static __device__ __forceinline__ void prepare() {}
 
   template <bool OCCLUDED, bool COUNT>
-  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t)
   {
     const uint32_t idx = ref & 0x7FFFFFFFu;
     const float4* gp = (const float4*)(P.accel.blobs + (size_t)idx * sizeof(GridCell));
@@ -443,7 +443,7 @@ template <int MODE, int LEVELS> struct CbvhLeaf
   static __device__ __forceinline__ void prepare() { cbvh_tables_init(); }
 
   template <bool OCCLUDED, bool COUNT>
-  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t)
   {
     const uint32_t idx = ref & 0x7FFFFFFFu;
     const uint8_t* blob = P.accel.blobs + (size_t)idx * P.accel.blobStride;

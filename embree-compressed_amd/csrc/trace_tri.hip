@@ -18,7 +18,7 @@ template <bool PLUECKER> struct TriLeaf
   static __device__ __forceinline__ void prepare() {}
 
   template <bool OCCLUDED, bool COUNT>
-  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc)
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t rayIdx)
   {
     const TriRecord* __restrict__ prims = P.accel.prims;
     const uint32_t first = ref & ((1u << TRI_START_BITS) - 1u);
@@ -44,7 +44,14 @@ template <bool PLUECKER> struct TriLeaf
           if (g + k >= nb) break;
           if (COUNT) wc.prims++;
           TriHit h;
-          const bool ok = PLUECKER ? pluecker(r, A[k], B[k], C[k], tfarBlock, h) : moeller(r, A[k], B[k], C[k], tfarBlock, h);
+          bool ok = PLUECKER ? pluecker(r, A[k], B[k], C[k], tfarBlock, h) : moeller(r, A[k], B[k], C[k], tfarBlock, h);
+          if (ok && P.exclOffsets) { // filter re-trace: a candidate the host filter rejected before stays rejected
+            const uint32_t e1 = P.exclOffsets[rayIdx + 1];
+            for (uint32_t e = P.exclOffsets[rayIdx]; e < e1; e++) {
+              const uint2 x = P.exclPairs[e];
+              if (x.x == __float_as_uint(A[k].w) && x.y == __float_as_uint(B[k].w)) ok = false;
+            }
+          }
           if (ok) {
             if (OCCLUDED) return true; // Occluded1EpilogM: any valid lane (no ray mask, no filter)
             // select_min over valid lanes, lowest lane wins ties (vfloat4_sse2.h:654-659)

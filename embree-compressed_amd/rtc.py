@@ -59,6 +59,14 @@ class RTCAMDSceneStats(C.Structure):
                 ("maxDepth", C.c_uint), ("reserved", C.c_uint)]
 
 
+class RTCFilterFunctionNArguments(C.Structure):
+    _fields_ = [("valid", C.POINTER(C.c_int)), ("geometryUserPtr", C.c_void_p), ("context", C.c_void_p), ("ray", C.c_void_p),
+                ("hit", C.c_void_p), ("N", C.c_uint)]
+
+
+FILTER_FUNC = C.CFUNCTYPE(None, C.POINTER(RTCFilterFunctionNArguments))
+
+
 class RTCInterpolateArguments(C.Structure):
     _fields_ = [("geometry", C.c_void_p), ("primID", C.c_uint), ("u", C.c_float), ("v", C.c_float), ("bufferType", C.c_int),
                 ("bufferSlot", C.c_uint), ("P", C.POINTER(C.c_float)), ("dPdu", C.POINTER(C.c_float)), ("dPdv", C.POINTER(C.c_float)),
@@ -126,6 +134,8 @@ def load_library(path=LIB_PATH):
         "rtcSetGeometrySubdivisionMode": (None, [vp, u, C.c_int]),
         "rtcSetGeometryTessellationRate": (None, [vp, C.c_float]),
         "rtcSetGeometryUserData": (None, [vp, vp]),
+        "rtcSetGeometryIntersectFilterFunction": (None, [vp, vp]),
+        "rtcSetGeometryOccludedFilterFunction": (None, [vp, vp]),
         "rtcNewScene": (vp, [vp]),
         "rtcRetainScene": (None, [vp]),
         "rtcReleaseScene": (None, [vp]),
@@ -297,6 +307,15 @@ class Scene:
         self._keep += [vpad, fs, fi, lv]
         self.device.check("add_subdiv")
         return gid
+
+    def set_filters(self, geom_id, intersect=None, occluded=None):
+        """intersect / occluded: FILTER_FUNC objects (kept alive by the scene wrapper) or None."""
+        g = self.lib.rtcGetGeometry(self.handle, geom_id)
+        self.lib.rtcSetGeometryIntersectFilterFunction(g, C.cast(intersect, C.c_void_p) if intersect is not None else None)
+        self.lib.rtcSetGeometryOccludedFilterFunction(g, C.cast(occluded, C.c_void_p) if occluded is not None else None)
+        self.lib.rtcCommitGeometry(g)
+        self._keep += [intersect, occluded]
+        self.device.check("set_filters")
 
     def set_vertex_attribute(self, geom_id, slot, values):
         """Bind a float32 [nv, k] (k <= 4) array as vertex attribute `slot` of an attached geometry and re-commit it."""
