@@ -1,0 +1,76 @@
+"""BASELINE config 5 (pathtracer): incoherent secondary rays and shadow rays that START ON the geometry, recorded
+wavefront-style from a primary pass (SURVEY.md section 8d "Config 5").  Origins on the surface are the hard case for
+parity: self-hits are avoided only by tnear (pathtracer_device.cpp uses tnear = 0.001), so GPU and oracle must agree
+on grazing and coplanar configurations.  Triangles (robust and fast path) and the eager subdivision path."""
+import importlib
+
+import numpy as np
+import pytest
+
+from helpers import INVALID, compare_hits, fill_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def _bounce(rtc, primary, seed):
+    """diffuse-ish bounce rays and shadow rays towards a point light from the hit points of `primary`"""
+    hit = primary["geomID"] != INVALID
+    p = primary[hit]
+    n = p.shape[0]
+    o = np.stack([p["org_x"] + p["tfar"] * p["dir_x"], p["org_y"] + p["tfar"] * p["dir_y"], p["org_z"] + p["tfar"] * p["dir_z"]], 1).astype(np.float32)
+    ng = np.stack([p["Ng_x"], p["Ng_y"], p["Ng_z"]], 1).astype(np.float64)
+    ng /= np.maximum(np.linalg.norm(ng, axis=1, keepdims=True), 1e-30)
+    d_in = np.stack([p["dir_x"], p["dir_y"], p["dir_z"]], 1)
+    ng[(ng * d_in).sum(1) > 0] *= -1  # face the incoming ray
+    rng = np.random.RandomState(seed)
+    r = rng.normal(size=(n, 3))
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    d = ng + 0.999 * r  # cosine-like lobe around the normal, including grazing directions
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sec = rtc.aligned_rayhits(n)
+    fill_rays(sec, o, d.astype(np.float32), tnear=0.001, tfar=np.inf)
+    light = np.array([50.0, 400.0, -120.0])
+    ld = light[None, :] - o
+    dist = np.linalg.norm(ld, axis=1)
+    sh = rtc.aligned_rays(n)
+    fill_rays(sh, o, (ld / dist[:, None]).astype(np.float32), tnear=0.001, tfar=dist.astype(np.float32))
+    return sec, sh
+
+
+@pytest.mark.parametrize("kind", ["tri.pluecker", "tri.moeller", "eager"])
+def test_secondary_and_shadow_rays_from_surface_points(rtc, po, bomberman, kind):
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    verts, fs, fi = bomberman
+    if kind.startswith("tri"):
+        dev = rtc.Device("tri_accel=bvh8.triangle4v" if kind == "tri.pluecker" else "tri_accel=bvh8.triangle4")
+        sc = rtc.Scene(dev)
+        tris = rtc.fan_triangulate(fs, fi)
+        sc.add_triangles(verts, tris)
+        sc.commit()
+        orc = po.TriangleScene(verts, tris, 0 if kind == "tri.pluecker" else 1)
+    else:
+        dev = rtc.Device("subdiv_accel=default")
+        sc = rtc.Scene(dev)
+        sc.add_subdiv(verts, fs, fi)
+        sc.set_levels(5, 3)
+        sc.commit()
+        orc = po.SubdivScene(sc.accel_data(2), sc.stats()["primBytes"], 2, 3)
+    raw = rg.make_primary_rays(640, 360)
+    prim = rtc.aligned_rayhits(raw.shape[0])
+    prim[:] = raw.reshape(-1).view(rtc.RAYHIT_DTYPE)
+    sc.intersect1M(prim)
+    sec, sh = _bounce(rtc, prim, seed=11)
+    assert sec.shape[0] > 100_000
+    want = sec.copy()
+    orc.intersect1M(want, nthreads=8)
+    sc.intersect1M(sec)
+    nh = compare_hits(sec, want, what=f"secondary {kind}")
+    assert 0 < nh < sec.shape[0]
+    wsh = sh.copy()
+    orc.occluded1M(wsh, nthreads=8)
+    sc.occluded1M(sh)
+    assert np.array_equal(sh["tfar"], wsh["tfar"])  # -inf where occluded, untouched elsewhere
+    assert 0 < np.isneginf(sh["tfar"]).sum() < sh.shape[0]
+    orc.free()
+    sc.release()
+    dev.release()
