@@ -236,6 +236,17 @@ void set_leaf_z(const Box3f& pb, F3 v1, F3 v2, F3 v3, F3 v4, float extent, uint8
 
 } // namespace
 
+// test hook (rtcamdDebugCbvhLeafCodec): the leaf quantiser on caller-supplied inputs
+void cbvh_debug_leaf_codec(const float box[6], const float v[12], float extent, uint8_t bytesOut[2], float* extentEstimate)
+{
+  Box3f pb;
+  for (int k = 0; k < 3; k++) { pb.lo[k] = box[k]; pb.hi[k] = box[3 + k]; }
+  F3 p[4];
+  for (int i = 0; i < 4; i++) { p[i].x = v[3 * i]; p[i].y = v[3 * i + 1]; p[i].z = v[3 * i + 2]; }
+  set_leaf_z(pb, p[0], p[1], p[2], p[3], extent, bytesOut);
+  if (extentEstimate) *extentEstimate = estimate_extent(pb, p[0], p[1], p[2], p[3]);
+}
+
 // Node::setAABB, compressed_node.h:406-448
 void cbvh_encode_node(const Box3f& P, const Box3f c[4], CbvhNode& out)
 {

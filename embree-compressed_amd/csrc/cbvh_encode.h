@@ -37,6 +37,7 @@ inline uint32_t cbvh_morton_x(uint32_t code);
 inline uint32_t cbvh_morton_y(uint32_t code);
 
 size_t cbvh_blob_bytes(unsigned C, CbvhMode mode);
+void cbvh_debug_leaf_codec(const float box[6], const float v[12], float extent, uint8_t bytesOut[2], float* extentEstimate);
 
 // Encode the sub-grid [x0,x1]x[y0,y1] (x1-x0 == y1-y0 == 2^C) of a tessellated patch into `blob`
 // (cbvh_blob_bytes(C,mode) bytes, 16-byte aligned) and return the world bounds for the outer BVH.

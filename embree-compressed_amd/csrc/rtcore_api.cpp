@@ -5,6 +5,7 @@
 #include "../../include/embree3/rtcore_amd.h"
 #include "rt_objects.h"
 #include "rt_trace.h"
+#include "cbvh_encode.h"
 #include "subdiv_tess.h"
 
 using namespace rtamd;
@@ -663,6 +664,11 @@ API const void* rtcamdGetAccelData(RTCScene h, unsigned int kind, size_t* byteSi
   CATCH_END(devOf(h))
   if (byteSize) *byteSize = 0;
   return nullptr;
+}
+
+API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate)
+{
+  cbvh_debug_leaf_codec(box, v, extent, bytesOut, extentEstimate);
 }
 
 API unsigned int rtcamdGetAccelRoot(RTCScene h)

@@ -168,6 +168,7 @@ def load_library(path=LIB_PATH):
         "rtcamdIntersect1MCounted": (None, [vp, C.POINTER(RTCIntersectContext), vp, u, sz, C.POINTER(RTCAMDTraceCounters)]),
         "rtcamdGetAccelData": (vp, [vp, u, C.POINTER(sz)]),
         "rtcamdGetAccelRoot": (u, [vp]),
+        "rtcamdDebugCbvhLeafCodec": (None, [vp, vp, C.c_float, vp, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

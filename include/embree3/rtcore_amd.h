@@ -96,6 +96,10 @@ RTC_API void rtcamdIntersect1MCounted(RTCScene scene, struct RTCIntersectContext
  * Test infrastructure: lets an external checker walk the exact structure the kernels traverse.
  * kind: 0 = BVH8 nodes, 1 = primitive records, 2 = subdiv leaf blobs, 3 = blob offset table. */
 RTC_API const void* rtcamdGetAccelData(RTCScene scene, unsigned int kind, size_t* byteSize);
+/* Test hook: the encoder's restatement of the fork's leaf quantiser (quantTris<4>::setZ / estimateExtent,
+ * kernels/geometry/compressed_leaf.h:193-251) on caller-supplied inputs: box = lower xyz, upper xyz of the parent box,
+ * v = the four corner vertices (12 floats).  Lets tests compare it with the reference header compiled in oracle/_ref. */
+RTC_API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate);
 /* Root reference of the BVH8 (encoding documented in DESIGN.md / csrc/accel.h). */
 RTC_API unsigned int rtcamdGetAccelRoot(RTCScene scene);
 

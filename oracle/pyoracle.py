@@ -66,6 +66,25 @@ def ref():
     return _ref
 
 
+_ref_fork = None
+
+
+def ref_fork():
+    """The fork's leaf codec header compiled in place (oracle/_ref/libref_fork.so), or None if absent."""
+    global _ref_fork
+    path = os.path.join(os.path.dirname(REF_PATH), "libref_fork.so")
+    if _ref_fork is None and os.path.exists(path):
+        R = C.CDLL(path)
+        vp = C.c_void_p
+        R.ref_fork_leaf_setZ.argtypes = [vp, vp, C.c_float, vp]
+        R.ref_fork_estimate_extent.restype = C.c_float
+        R.ref_fork_estimate_extent.argtypes = [vp, vp]
+        R.ref_fork_leaf_getZ.argtypes = [C.c_ubyte, C.c_ubyte, C.c_float, C.c_float, vp]
+        R.ref_fork_leaf_delta.restype = C.c_float
+        _ref_fork = R
+    return _ref_fork
+
+
 class TriangleScene:
     """mode 0: BVH8/Triangle4v/robust/Pluecker; mode 1: BVH8/Triangle4/fast/Moeller."""
 

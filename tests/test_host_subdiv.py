@@ -225,3 +225,50 @@ def test_oracle_hits_match_across_subdiv_modes(rtc, po, bomberman):
     # the cBVH's quantized boxes are not strictly conservative (fork approximation): a few rays see a farther triangle
     close = np.isclose(a["tfar"][both], b["tfar"][both], rtol=1e-3, atol=1e-3)
     assert close.mean() > 0.995
+
+
+def test_leaf_quantiser_matches_the_forks_header(rtc, po):
+    """quantTris<4>::setZ / estimateExtent / getZ / getDelta of kernels/geometry/compressed_leaf.h, compiled where it lies
+    (oracle/_ref/libref_fork.so, -ffp-contract=off), against the encoder's restatement (test hook of the product library)
+    and against the decode formula the kernel and the oracle use.  Bit for bit."""
+    import ctypes as C
+    R = po.ref_fork()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_fork.so not built (no reference tree)")
+    L = rtc.lib()
+    rng = np.random.RandomState(21)
+    checked = 0
+    for trial in range(4000):
+        lo = (rng.randn(3) * 2).astype(np.float32)
+        hi = (lo + np.abs(rng.randn(3)).astype(np.float32) * (0.01 if trial % 3 == 0 else 1.0) + np.float32(1e-3)).astype(np.float32)
+        if trial % 97 == 0:
+            hi[2] = lo[2]  # flat box: setZero branch
+        box = np.concatenate([lo, hi]).astype(np.float32)
+        # four corner vertices roughly over the box corners, heights scattered inside and outside the z range
+        xy = np.array([[lo[0], lo[1]], [hi[0], lo[1]], [lo[0], hi[1]], [hi[0], hi[1]]], np.float32)
+        xy = (xy + rng.randn(4, 2).astype(np.float32) * 0.05 * (hi[:2] - lo[:2])).astype(np.float32)
+        z = (lo[2] + (hi[2] - lo[2]) * rng.uniform(-0.4, 1.4, 4)).astype(np.float32)
+        v = np.ascontiguousarray(np.concatenate([xy, z[:, None]], 1).astype(np.float32))
+        ext_ref = R.ref_fork_estimate_extent(box.ctypes.data, v.ctypes.data)
+        got_b, want_b = np.zeros(2, np.uint8), np.zeros(2, np.uint8)
+        ext = C.c_float(0)
+        extent_in = float(np.float32(ext_ref if trial % 2 else rng.uniform(0, 0.5)))
+        L.rtcamdDebugCbvhLeafCodec(box.ctypes.data, v.ctypes.data, extent_in, got_b.ctypes.data, C.byref(ext))
+        R.ref_fork_leaf_setZ(box.ctypes.data, v.ctypes.data, extent_in, want_b.ctypes.data)
+        if np.isfinite(ext_ref):
+            assert np.float32(ext.value) == np.float32(ext_ref), (trial, ext.value, ext_ref)
+            assert np.array_equal(got_b, want_b), (trial, got_b, want_b)
+            checked += 1
+    assert checked > 3500
+    # getDelta() = rcp(16.f) is rcpss + one Newton step in the reference (common/math/math.h:60-75): 0x3D7FFFFF on Intel
+    # CPUs, exactly 0.0625 where rcpss is exact for powers of two.  Device code and oracle use the exact 0.0625
+    # (DESIGN.md section 1: rcp is a correctly rounded division on the GPU).
+    delta = np.float32(R.ref_fork_leaf_delta())
+    assert abs(float(delta) - 0.0625) <= 2.0 ** -28
+    out = np.zeros(4, np.float32)
+    for z12, z34 in ((0x00, 0xff), (0x1e, 0x73), (0xa5, 0x5a), (0xff, 0x00)):
+        for rng_, off in ((np.float32(0.37), np.float32(-1.25)), (np.float32(1e-3), np.float32(17.5)), (np.float32(251.0), np.float32(0.0))):
+            R.ref_fork_leaf_getZ(z12, z34, float(rng_), float(off), out.ctypes.data)
+            rcpF = delta * rng_  # same operation order as the device / oracle decode: (delta*range) * nibble + offset
+            want = [off + rcpF * np.float32(z12 >> 4), off + rcpF * np.float32(z12 & 15), off + rcpF * np.float32(z34 >> 4), off + rcpF * np.float32(z34 & 15)]
+            assert np.array_equal(out, np.array(want, np.float32))
