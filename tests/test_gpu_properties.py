@@ -1,0 +1,87 @@
+"""Size-independent properties at the full sizes of BASELINE.json (the oracle needs minutes for these batches, the
+properties need no oracle): on the metric scene (bomberman subdiv L6 / C3) and on the triangle scene, with 4 M random rays
+on device-resident batches:
+  * split invariance   one 4 M batch == four 1 M batches (a stream is M independent single-ray calls, rtcore.cpp:403-432)
+  * stride invariance  the same rays embedded in 96-byte records give the same records
+  * idempotence        tracing the traced batch again changes nothing (the hit is found again at t == tfar and accepted by
+                       t <= tfar; misses stay untouched)
+  * any-hit vs closest an occluded ray (tfar = -inf) is exactly a ray for which the closest-hit query found something
+                       (triangles and the eager path; the fork's any-hit is a stub in all compressed modes, compressed.h:754-756)
+  * determinism        two runs of the same batch give the same bytes although the work distribution is dynamic
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M = 4_000_000
+
+
+def _scene(rtc, bomberman, kind):
+    verts, fs, fi = bomberman
+    if kind == "tri":
+        dev = rtc.Device("tri_accel=bvh8.triangle4v")
+        sc = rtc.Scene(dev)
+        sc.add_triangles(verts, rtc.fan_triangulate(fs, fi))
+    else:
+        dev = rtc.Device("subdiv_accel=" + kind)
+        sc = rtc.Scene(dev)
+        sc.add_subdiv(verts, fs, fi)
+        sc.set_levels(6, 3)
+    sc.commit()
+    return dev, sc
+
+
+@pytest.mark.parametrize("kind", ["tri", "bvh4.compressed.leaf", "default", "bvh4.compressed.grid"])
+def test_full_size_properties(rtc, bomberman, kind):
+    import torch
+
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    verts = bomberman[0]
+    dev, sc = _scene(rtc, bomberman, kind)
+    dev.set_stream(torch.cuda.current_stream().cuda_stream)  # clones (torch's stream) and traces are then stream-ordered
+    rays = torch.from_numpy(rg.make_random_rays(M, verts.min(0), verts.max(0), seed=2024)).cuda()  # [M, 80] bytes
+    whole = rays.clone()
+    sc.intersect1M(whole)
+    dev.synchronize()
+    hits = int((whole.view(torch.int32)[:, 18] != -1).sum().item())
+    assert 0.1 * M < hits < 0.5 * M
+    # split invariance
+    parts = rays.clone()
+    for k in range(4):
+        sc.intersect1M(parts[k * (M // 4):(k + 1) * (M // 4)])
+    dev.synchronize()
+    assert torch.equal(parts, whole)
+    # determinism under dynamic scheduling
+    again = rays.clone()
+    sc.intersect1M(again)
+    dev.synchronize()
+    assert torch.equal(again, whole)
+    # stride invariance (96-byte records, payload in the first 80)
+    wide = torch.zeros((M // 4, 96), dtype=torch.uint8, device="cuda")
+    wide[:, :80] = rays[: M // 4]
+    sc.intersect1M(wide)
+    dev.synchronize()
+    assert torch.equal(wide[:, :80], whole[: M // 4]) and int(wide[:, 80:].sum().item()) == 0
+    # idempotence
+    twice = whole.clone()
+    sc.intersect1M(twice)
+    dev.synchronize()
+    if kind in ("tri", "default", "bvh4.compressed.grid"):
+        assert torch.equal(twice, whole)
+    else:  # fork leaf mode: a blob's local ray depends on the tfar it sees; IDs must still agree
+        same = (twice.view(torch.int32)[:, 17:19] == whole.view(torch.int32)[:, 17:19]).all(1).float().mean().item()
+        assert same > 0.999
+    # any-hit vs closest hit
+    if kind in ("tri", "default"):
+        occ = rays[:, :48].contiguous().clone()
+        sc.occluded1M(occ)
+        dev.synchronize()
+        occluded = torch.isneginf(occ.view(torch.float32)[:, 8])
+        assert torch.equal(occluded, whole.view(torch.int32)[:, 18] != -1)
+        untouched = ~occluded
+        assert torch.equal(occ[untouched], rays[:, :48][untouched])
+    sc.release()
+    dev.release()
