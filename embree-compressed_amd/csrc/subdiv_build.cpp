@@ -4,7 +4,46 @@
 #include "cbvh_encode.h"
 #include "subdiv_tess.h"
 
+#include <atomic>
+#include <functional>
+#include <thread>
+
 namespace rtamd {
+
+// Host-side parallel loop for the commit-time builders: contiguous chunks handed out dynamically.
+unsigned host_threads(const Device* dev)
+{
+  unsigned n = dev->numThreads > 0 ? (unsigned)dev->numThreads : std::thread::hardware_concurrency();
+  return n ? std::min(n, 64u) : 1u;
+}
+void parallel_for_range(size_t count, unsigned threads, const std::function<void(size_t, size_t)>& body)
+{
+  if (count == 0) return;
+  if (threads <= 1 || count < 2) { body(0, count); return; }
+  const size_t chunk = std::max<size_t>(1, count / (threads * 8));
+  std::atomic<size_t> next{0};
+  std::exception_ptr err;
+  std::mutex errMutex;
+  auto work = [&]() {
+    for (;;) {
+      const size_t b = next.fetch_add(chunk);
+      if (b >= count) return;
+      try {
+        body(b, std::min(count, b + chunk));
+      } catch (...) {
+        std::lock_guard<std::mutex> g(errMutex);
+        if (!err) err = std::current_exception();
+        next.store(count);
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+  if (err) std::rethrow_exception(err);
+}
 
 namespace {
 
@@ -82,17 +121,25 @@ void build_cbvh(Scene* s, const std::vector<PatchGrid>& grids, Accel& A, CbvhMod
   if (nblobs >= 0x7FFFFFFFull || nblobs * stride > ((size_t)1 << 40)) RT_THROW(RTC_ERROR_OUT_OF_MEMORY, "too many cBVH leaves");
   A.blobs.resize(nblobs * stride);
   std::vector<BuildPrim> bp(nblobs);
-  size_t b = 0;
-  for (const PatchGrid& pg : grids)
-    for (unsigned y = 0; y < pg.n; y += sub)
-      for (unsigned x = 0; x < pg.n; x += sub) {
-        Box3 bounds;
-        cbvh_encode(pg, x, x + sub, y, y + sub, C, mode, A.blobs.data() + b * stride, bounds);
-        bp[b].box = bounds;
-        bp[b].id = (uint32_t)b;
-        s->bounds.extend(bounds);
-        b++;
-      }
+  // the blobs are independent of each other: encode them on all host threads (rtcCommitScene is internally parallel in
+  // the reference too, scene.cpp:727-786); blob index = position in the (grid, y, x) order, as before
+  std::vector<size_t> firstBlob(grids.size() + 1, 0);
+  for (size_t g = 0; g < grids.size(); g++) firstBlob[g + 1] = firstBlob[g] + (size_t)(grids[g].n / sub) * (grids[g].n / sub);
+  parallel_for_range(grids.size(), host_threads(s->device), [&](size_t g0, size_t g1) {
+    for (size_t g = g0; g < g1; g++) {
+      const PatchGrid& pg = grids[g];
+      size_t b = firstBlob[g];
+      for (unsigned y = 0; y < pg.n; y += sub)
+        for (unsigned x = 0; x < pg.n; x += sub) {
+          Box3 bounds;
+          cbvh_encode(pg, x, x + sub, y, y + sub, C, mode, A.blobs.data() + b * stride, bounds);
+          bp[b].box = bounds;
+          bp[b].id = (uint32_t)b;
+          b++;
+        }
+    }
+  });
+  for (size_t b = 0; b < nblobs; b++) s->bounds.extend(bp[b].box);
   auto makeLeaf = [&](const BuildPrim* prims, size_t begin, size_t end) -> uint32_t { return REF_LEAF | prims[begin].id; };
   BuildSettings cfg;
   cfg.blockSize = 1; cfg.minLeaf = 1; cfg.maxLeaf = 1;
