@@ -78,7 +78,7 @@ API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop)
   case RTC_DEVICE_PROPERTY_VERSION_PATCH: return RTC_VERSION_PATCH;
   case RTC_DEVICE_PROPERTY_NATIVE_RAY4_SUPPORTED:
   case RTC_DEVICE_PROPERTY_NATIVE_RAY8_SUPPORTED:
-  case RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED: return 0;
+  case RTC_DEVICE_PROPERTY_NATIVE_RAY16_SUPPORTED: return 0; // accepted and traced as single rays, no native packet kernels
   case RTC_DEVICE_PROPERTY_RAY_STREAM_SUPPORTED: return 1;
   case RTC_DEVICE_PROPERTY_RAY_MASK_SUPPORTED: return 0;          // EMBREE_RAY_MASK default OFF (CMakeLists.txt:114)
   case RTC_DEVICE_PROPERTY_BACKFACE_CULLING_ENABLED: return 0;    // CMakeLists.txt:115
@@ -542,21 +542,131 @@ API void rtcOccluded1Mp(RTCScene h, struct RTCIntersectContext* ctx, struct RTCR
   CATCH_END(devOf(h))
 }
 
-#define UNSUPPORTED_TRACE(NAME, ...)                      \
-  API void NAME(__VA_ARGS__)                              \
-  {                                                       \
-    CATCH_BEGIN unsupported(#NAME); CATCH_END(devOf(scene)) \
+// ---- packets, packet streams, SoA streams -----------------------------------------------------------------------------
+// rtcIntersect4/8/16 (rtcore.cpp:306-401), rtcIntersectNM (:450-492), rtcIntersectNp (:494-539) and their occluded
+// twins: the device has one kernel family - single rays in AoS records - so the active rays of a packet / stream are
+// gathered into one AoS batch, traced like rtcIntersect1M, and tfar (+ the hit) scattered back.  Inactive lanes
+// (valid[i] == 0) are not touched.  Results are those of N independent rtcIntersect1 calls, which is what the reference
+// guarantees for packets as well.
+template <typename Get, typename Put>
+static void trace_gathered(Scene* s, RTCIntersectContext* ctx, bool occluded, size_t total, Get get, Put put)
+{
+  std::vector<RTCRayHit> aos;
+  std::vector<size_t> idx;
+  aos.reserve(total);
+  idx.reserve(total);
+  for (size_t i = 0; i < total; i++) {
+    RTCRayHit r;
+    if (get(i, r)) {
+      aos.push_back(r);
+      idx.push_back(i);
+    }
   }
-UNSUPPORTED_TRACE(rtcIntersect4, const int*, RTCScene scene, struct RTCIntersectContext*, struct RTCRayHit4*)
-UNSUPPORTED_TRACE(rtcIntersect8, const int*, RTCScene scene, struct RTCIntersectContext*, struct RTCRayHit8*)
-UNSUPPORTED_TRACE(rtcIntersect16, const int*, RTCScene scene, struct RTCIntersectContext*, struct RTCRayHit16*)
-UNSUPPORTED_TRACE(rtcIntersectNM, RTCScene scene, struct RTCIntersectContext*, struct RTCRayHitN*, unsigned int, unsigned int, size_t)
-UNSUPPORTED_TRACE(rtcIntersectNp, RTCScene scene, struct RTCIntersectContext*, const struct RTCRayHitNp*, unsigned int)
-UNSUPPORTED_TRACE(rtcOccluded4, const int*, RTCScene scene, struct RTCIntersectContext*, struct RTCRay4*)
-UNSUPPORTED_TRACE(rtcOccluded8, const int*, RTCScene scene, struct RTCIntersectContext*, struct RTCRay8*)
-UNSUPPORTED_TRACE(rtcOccluded16, const int*, RTCScene scene, struct RTCIntersectContext*, struct RTCRay16*)
-UNSUPPORTED_TRACE(rtcOccludedNM, RTCScene scene, struct RTCIntersectContext*, struct RTCRayN*, unsigned int, unsigned int, size_t)
-UNSUPPORTED_TRACE(rtcOccludedNp, RTCScene scene, struct RTCIntersectContext*, const struct RTCRayNp*, unsigned int)
+  if (aos.empty()) return;
+  if (aos.size() > 0xFFFFFFFFull) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "too many rays in one call");
+  trace_call(s, aos.data(), (uint32_t)aos.size(), sizeof(RTCRayHit), occluded, ctx); // any-hit reads the first 48 bytes of each record
+  for (size_t k = 0; k < aos.size(); k++) put(idx[k], aos[k]);
+}
+
+static void trace_packets(RTCScene h, RTCIntersectContext* ctx, const int* valid, void* packets, unsigned N, unsigned M, size_t byteStride,
+                          bool occluded)
+{
+  VERIFY(h);
+  VERIFY(packets);
+  auto ray_of = [&](size_t i) { return (RTCRayN*)((char*)packets + (i / N) * byteStride); };
+  trace_gathered(
+      S(h), ctx, occluded, (size_t)N * M,
+      [&](size_t i, RTCRayHit& r) {
+        const unsigned l = (unsigned)(i % N);
+        if (valid && valid[l] == 0) return false;
+        RTCRayN* rn = ray_of(i);
+        r.ray = rtcGetRayFromRayN(rn, N, l);
+        if (occluded) {
+          memset(&r.hit, 0, sizeof(r.hit));
+          r.hit.geomID = r.hit.primID = r.hit.instID[0] = RTC_INVALID_GEOMETRY_ID;
+        } else
+          r.hit = rtcGetHitFromHitN(RTCRayHitN_HitN((RTCRayHitN*)rn, N), N, l);
+        return true;
+      },
+      [&](size_t i, const RTCRayHit& r) {
+        const unsigned l = (unsigned)(i % N);
+        RTCRayN* rn = ray_of(i);
+        RTCRayN_tfar(rn, N, l) = r.ray.tfar;
+        if (!occluded) rtcCopyHitToHitN(RTCRayHitN_HitN((RTCRayHitN*)rn, N), &r.hit, N, l);
+      });
+}
+
+#define PACKET_TRACE(W)                                                                                                        \
+  API void rtcIntersect##W(const int* valid, RTCScene scene, struct RTCIntersectContext* ctx, struct RTCRayHit##W* rayhit)      \
+  {                                                                                                                            \
+    CATCH_BEGIN trace_packets(scene, ctx, valid, rayhit, W, 1, 0, false); CATCH_END(devOf(scene))                              \
+  }                                                                                                                            \
+  API void rtcOccluded##W(const int* valid, RTCScene scene, struct RTCIntersectContext* ctx, struct RTCRay##W* ray)             \
+  {                                                                                                                            \
+    CATCH_BEGIN trace_packets(scene, ctx, valid, ray, W, 1, 0, true); CATCH_END(devOf(scene))                                  \
+  }
+PACKET_TRACE(4)
+PACKET_TRACE(8)
+PACKET_TRACE(16)
+
+API void rtcIntersectNM(RTCScene scene, struct RTCIntersectContext* ctx, struct RTCRayHitN* rayhit, unsigned int N, unsigned int M, size_t byteStride)
+{
+  CATCH_BEGIN
+  if (N == 0 || M == 0) return;
+  trace_packets(scene, ctx, nullptr, rayhit, N, M, byteStride, false);
+  CATCH_END(devOf(scene))
+}
+API void rtcOccludedNM(RTCScene scene, struct RTCIntersectContext* ctx, struct RTCRayN* ray, unsigned int N, unsigned int M, size_t byteStride)
+{
+  CATCH_BEGIN
+  if (N == 0 || M == 0) return;
+  trace_packets(scene, ctx, nullptr, ray, N, M, byteStride, true);
+  CATCH_END(devOf(scene))
+}
+
+static void trace_np(RTCScene h, RTCIntersectContext* ctx, const RTCRayNp& ray, const RTCHitNp* hit, unsigned N)
+{
+  VERIFY(h);
+  const bool occluded = hit == nullptr;
+  trace_gathered(
+      S(h), ctx, occluded, N,
+      [&](size_t i, RTCRayHit& r) {
+        r.ray.org_x = ray.org_x[i]; r.ray.org_y = ray.org_y[i]; r.ray.org_z = ray.org_z[i]; r.ray.tnear = ray.tnear[i];
+        r.ray.dir_x = ray.dir_x[i]; r.ray.dir_y = ray.dir_y[i]; r.ray.dir_z = ray.dir_z[i]; r.ray.time = ray.time ? ray.time[i] : 0.f;
+        r.ray.tfar = ray.tfar[i];
+        r.ray.mask = ray.mask ? ray.mask[i] : 0xFFFFFFFFu; r.ray.id = ray.id ? ray.id[i] : 0u; r.ray.flags = ray.flags ? ray.flags[i] : 0u;
+        memset(&r.hit, 0, sizeof(r.hit));
+        r.hit.geomID = r.hit.primID = r.hit.instID[0] = RTC_INVALID_GEOMETRY_ID;
+        if (hit) {
+          r.hit.Ng_x = hit->Ng_x[i]; r.hit.Ng_y = hit->Ng_y[i]; r.hit.Ng_z = hit->Ng_z[i]; r.hit.u = hit->u[i]; r.hit.v = hit->v[i];
+          r.hit.primID = hit->primID[i]; r.hit.geomID = hit->geomID[i];
+          if (hit->instID[0]) r.hit.instID[0] = hit->instID[0][i];
+        }
+        return true;
+      },
+      [&](size_t i, const RTCRayHit& r) {
+        ray.tfar[i] = r.ray.tfar;
+        if (hit) {
+          hit->Ng_x[i] = r.hit.Ng_x; hit->Ng_y[i] = r.hit.Ng_y; hit->Ng_z[i] = r.hit.Ng_z; hit->u[i] = r.hit.u; hit->v[i] = r.hit.v;
+          hit->primID[i] = r.hit.primID; hit->geomID[i] = r.hit.geomID;
+          if (hit->instID[0]) hit->instID[0][i] = r.hit.instID[0];
+        }
+      });
+}
+API void rtcIntersectNp(RTCScene scene, struct RTCIntersectContext* ctx, const struct RTCRayHitNp* rayhit, unsigned int N)
+{
+  CATCH_BEGIN
+  VERIFY(rayhit);
+  if (N) trace_np(scene, ctx, rayhit->ray, &rayhit->hit, N);
+  CATCH_END(devOf(scene))
+}
+API void rtcOccludedNp(RTCScene scene, struct RTCIntersectContext* ctx, const struct RTCRayNp* ray, unsigned int N)
+{
+  CATCH_BEGIN
+  VERIFY(ray);
+  if (N) trace_np(scene, ctx, *ray, nullptr, N);
+  CATCH_END(devOf(scene))
+}
 
 // ---- BVH builder API: declared for link compatibility ------------------------------------------------------------------
 API RTCBVH rtcNewBVH(RTCDevice h)

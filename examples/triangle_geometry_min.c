@@ -161,8 +161,29 @@ int main(int argc, char** argv)
   int nstream = 0;
   for (int i = 0; i < W * H; i++) nstream += stream[i].hit.geomID != RTC_INVALID_GEOMETRY_ID;
   if (nstream != nhit) { fprintf(stderr, "stream hits %d != single-ray hits %d\n", nstream, nhit); bad++; }
-  /* error convention: packets are not on the device path */
-  rtcIntersect4(NULL, scene, &ctx, NULL);
+  /* a packet of four of the same rays (lane 2 masked out) must reproduce the single-ray answers */
+  {
+    struct RTCRayHit4 p4;
+    int valid[4] = {-1, -1, 0, -1};
+    const int pick[4] = {0, W * H / 2 + W / 2, 5, W * H - 1};
+    for (int l = 0; l < 4; l++) {
+      const struct RTCRayHit* s = &stream[pick[l]]; /* already traced: its hit must be found again at the same distance */
+      p4.ray.org_x[l] = s->ray.org_x; p4.ray.org_y[l] = s->ray.org_y; p4.ray.org_z[l] = s->ray.org_z; p4.ray.tnear[l] = 0.f;
+      p4.ray.dir_x[l] = s->ray.dir_x; p4.ray.dir_y[l] = s->ray.dir_y; p4.ray.dir_z[l] = s->ray.dir_z; p4.ray.time[l] = 0.f;
+      p4.ray.tfar[l] = INFINITY; p4.ray.mask[l] = 0xFFFFFFFFu; p4.ray.id[l] = (unsigned)l; p4.ray.flags[l] = 0;
+      p4.hit.geomID[l] = p4.hit.primID[l] = p4.hit.instID[0][l] = RTC_INVALID_GEOMETRY_ID;
+    }
+    rtcIntersect4(valid, scene, &ctx, &p4);
+    for (int l = 0; l < 4; l++) {
+      const struct RTCRayHit* s = &stream[pick[l]];
+      if (l == 2) { if (p4.hit.geomID[l] != RTC_INVALID_GEOMETRY_ID || p4.ray.tfar[l] != INFINITY) { fprintf(stderr, "masked lane touched\n"); bad++; } }
+      else if (p4.hit.geomID[l] != s->hit.geomID || p4.hit.primID[l] != s->hit.primID || (s->hit.geomID != RTC_INVALID_GEOMETRY_ID && p4.ray.tfar[l] != s->ray.tfar)) {
+        fprintf(stderr, "packet lane %d differs from the stream\n", l); bad++;
+      }
+    }
+  }
+  /* error convention: an entry point that is not provided reports through the device error state */
+  rtcNewBVH(dev);
   if (g_errors != 1 || rtcGetDeviceError(dev) != RTC_ERROR_INVALID_OPERATION) { fprintf(stderr, "error convention broken\n"); bad++; }
   free(stream);
   rtcReleaseScene(scene);

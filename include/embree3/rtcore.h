@@ -483,7 +483,7 @@ RTC_API void rtcOccluded1M(RTCScene scene, struct RTCIntersectContext* context, 
 /* pointer streams are gathered into one device batch */
 RTC_API void rtcIntersect1Mp(RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit** rayhit, unsigned int M);
 RTC_API void rtcOccluded1Mp(RTCScene scene, struct RTCIntersectContext* context, struct RTCRay** ray, unsigned int M);
-/* not on the device path: raise RTC_ERROR_INVALID_OPERATION */
+/* packets / packet streams / SoA streams: the active rays are gathered into one single-ray batch */
 RTC_API void rtcIntersect4(const int* valid, RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit4* rayhit);
 RTC_API void rtcIntersect8(const int* valid, RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit8* rayhit);
 RTC_API void rtcIntersect16(const int* valid, RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit16* rayhit);

@@ -63,9 +63,9 @@ def test_error_conventions(rtc):
     # host-only device: tracing is refused, never emulated
     sc.intersect1M(rays, check=False)
     assert dev.error() == rtc.RTC_ERROR_INVALID_OPERATION
-    # packet entry points are not on the device path (rtcore.cpp:429,680 convention)
+    # packet entry points gather their active rays into a single-ray batch: null packet -> INVALID_ARGUMENT
     lib.rtcIntersect4(None, sc.handle, None, None)
-    assert dev.error() == rtc.RTC_ERROR_INVALID_OPERATION
+    assert dev.error() == rtc.RTC_ERROR_INVALID_ARGUMENT
     # unsupported geometry types
     assert not lib.rtcNewGeometry(dev.handle, rtc.RTC_GEOMETRY_TYPE_QUAD)
     assert dev.error() == rtc.RTC_ERROR_INVALID_OPERATION
