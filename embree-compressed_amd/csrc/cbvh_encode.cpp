@@ -334,8 +334,8 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
   H->geomID = pg.geomID;
   H->primID = pg.primID;
   const float fn = (float)pg.n;
-  H->uv0x = (float)x0 / fn; H->uv0y = (float)y0 / fn;           // grid_u/grid_v of the first vertex
-  H->uv1x = (float)x1 / fn - H->uv0x; H->uv1y = (float)y1 / fn - H->uv0y; // :85-86
+  H->uv0x = pg.u0 + (float)x0 / fn; H->uv0y = pg.v0 + (float)y0 / fn;           // grid_u/grid_v of the first vertex
+  H->uv1x = (pg.u0 + (float)x1 / fn) - H->uv0x; H->uv1y = (pg.v0 + (float)y1 / fn) - H->uv0y; // :85-86
   H->rcp_edges = 1.f / (float)(1u << C);                         // :88-89
   H->elems = (uint32_t)elems;
   H->grid_width = width;

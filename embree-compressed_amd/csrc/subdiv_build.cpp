@@ -76,7 +76,7 @@ void build_eager(Scene* s, const std::vector<PatchGrid>& grids, Accel& A)
             const size_t k = (size_t)(cy + r) * w + (cx + q);
             g.px[r * 3 + q] = pg.x[k]; g.py[r * 3 + q] = pg.y[k]; g.pz[r * 3 + q] = pg.z[k];
             // UV encoding, grid_soa.cpp:48-52: (int) clamp(u * (0x10000/8), 0, 0xFFFF), v in the high half
-            const float u = (float)(cx + q) / fn, v = (float)(cy + r) / fn;
+            const float u = pg.u0 + (float)(cx + q) / fn, v = pg.v0 + (float)(cy + r) / fn;
             const int iu = (int)fminf(fmaxf(u * (0x10000 / 8.0f), 0.0f), (float)0xFFFF);
             const int iv = (int)fminf(fmaxf(v * (0x10000 / 8.0f), 0.0f), (float)0xFFFF);
             g.uv[r * 3 + q] = ((uint32_t)iv << 16) | (uint32_t)iu;

@@ -335,9 +335,113 @@ struct NormalEval
 
 } // namespace
 
-// Level 0 of a subdivision geometry: control vertices as they are, one 2x2 grid per valid quad face.
-// A face is valid if it is not a hole, its indices are in range and its vertices are finite (SubdivMesh::valid).
-static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std::vector<unsigned>& facePrim)
+// What a face of the control mesh became in the base level of the refiner.
+struct FaceMap
+{
+  unsigned primID;   // face number in the geometry
+  unsigned corners;  // 4: the face is one grid; N != 4: the face was split into N sub-patches (see below)
+  unsigned sub;      // sub-patch number (0 for quads)
+};
+
+// One generic Catmull-Clark step on a polygon mesh (faces of any arity >= 3): every N-gon becomes N quads,
+// sub-quad k = (vertex point of corner k, edge point of edge k -> k+1, face point, edge point of edge k-1 -> k), the
+// vertex order of the reference's sub-patches (GeneralCatmullClarkPatch::subdivide, catmullclark_patch.h:442-483:
+// ring[0] = corner, ring[1] = next edge, ring[2] = centre, ring[3] = previous edge).  Same rules as Refiner::refine.
+static void refine_polygons(const std::vector<D3>& P, const std::vector<std::vector<uint32_t>>& faces, RTCSubdivisionMode mode, Level& out)
+{
+  const size_t nV = P.size(), nF = faces.size();
+  std::vector<Acc> acc(nV);
+  std::vector<D3> fp(nF);
+  struct Edge { uint32_t idx, count, a, b; D3 sumFp; };
+  std::unordered_map<uint64_t, Edge> edges;
+  edges.reserve(nF * 4);
+  for (size_t f = 0; f < nF; f++) {
+    const std::vector<uint32_t>& q = faces[f];
+    D3 c;
+    for (uint32_t v : q) c += P[v];
+    fp[f] = c * (1.0 / (double)q.size());
+    for (size_t k = 0; k < q.size(); k++) {
+      acc[q[k]].sumF += fp[f];
+      acc[q[k]].nf++;
+      const uint32_t a = q[k], b = q[(k + 1) % q.size()];
+      auto it = edges.find(edge_key(a, b));
+      if (it == edges.end()) edges.emplace(edge_key(a, b), Edge{(uint32_t)edges.size(), 1u, a, b, fp[f]});
+      else { it->second.count++; it->second.sumFp += fp[f]; }
+    }
+  }
+  for (auto& kv : edges) {
+    const Edge& e = kv.second;
+    acc[e.a].sumN += P[e.b]; acc[e.a].ne++;
+    acc[e.b].sumN += P[e.a]; acc[e.b].ne++;
+    if (e.count != 2) {
+      acc[e.a].sumB += P[e.b]; acc[e.a].nb++;
+      acc[e.b].sumB += P[e.a]; acc[e.b].nb++;
+    }
+  }
+  // boundary classification exactly as Refiner::classify on the first level
+  const size_t nE = edges.size();
+  out.n = 1;
+  out.P.resize(nV + nE + nF);
+  out.pinned.assign(out.P.size(), 0);
+  out.bpin.assign(out.P.size(), 0);
+  for (size_t v = 0; v < nV; v++) {
+    const Acc& a = acc[v];
+    if (a.nb == 0) {
+      if (mode == RTC_SUBDIVISION_MODE_PIN_ALL) out.pinned[v] = 1;
+      continue;
+    }
+    if (a.nb != 2) out.pinned[v] = 1;
+    switch (mode) {
+    case RTC_SUBDIVISION_MODE_PIN_CORNERS: if (a.nf == 1) out.pinned[v] = 1; break;
+    case RTC_SUBDIVISION_MODE_PIN_BOUNDARY: out.pinned[v] = 1; out.bpin[v] = 1; break;
+    case RTC_SUBDIVISION_MODE_PIN_ALL: out.pinned[v] = 1; out.bpin[v] = 1; break;
+    default: break;
+    }
+  }
+  const bool pinAll = mode == RTC_SUBDIVISION_MODE_PIN_ALL;
+  for (size_t v = 0; v < nV; v++) {
+    const Acc& a = acc[v];
+    if (out.pinned[v] || a.ne == 0) out.P[v] = P[v];
+    else if (a.nb == 0) {
+      const double n = (double)a.ne;
+      out.P[v] = a.sumF * (1.0 / (n * n)) + a.sumN * (1.0 / (n * n)) + P[v] * ((n - 2.0) / n);
+    } else
+      out.P[v] = P[v] * 0.75 + a.sumB * 0.125;
+  }
+  for (auto& kv : edges) {
+    const Edge& e = kv.second;
+    const size_t id = nV + e.idx;
+    if (e.count == 2 && !pinAll) out.P[id] = (P[e.a] + P[e.b] + e.sumFp) * 0.25;
+    else {
+      out.P[id] = (P[e.a] + P[e.b]) * 0.5;
+      if (out.bpin[e.a] && out.bpin[e.b]) { out.pinned[id] = 1; out.bpin[id] = 1; }
+    }
+    if (pinAll) out.pinned[id] = 1;
+  }
+  for (size_t f = 0; f < nF; f++) {
+    out.P[nV + nE + f] = fp[f];
+    if (pinAll) out.pinned[nV + nE + f] = 1;
+  }
+  out.grid.clear();
+  for (size_t f = 0; f < nF; f++) {
+    const std::vector<uint32_t>& q = faces[f];
+    const size_t N = q.size();
+    const uint32_t F = (uint32_t)(nV + nE + f);
+    for (size_t k = 0; k < N; k++) {
+      const uint32_t eNext = (uint32_t)(nV + edges.find(edge_key(q[k], q[(k + 1) % N]))->second.idx);
+      const uint32_t ePrev = (uint32_t)(nV + edges.find(edge_key(q[(k + N - 1) % N], q[k]))->second.idx);
+      out.grid.push_back({q[k], eNext, ePrev, F}); // row-major 2x2: (0,0) corner, (1,0) next edge, (0,1) previous edge, (1,1) centre
+    }
+  }
+}
+
+// Base level of a subdivision geometry for the refiner.  All faces quads: level 0 = the control mesh, one 2x2 grid
+// per valid face (`firstStep` = true: the boundary classification still has to run).  Otherwise: the mesh after ONE
+// generic Catmull-Clark step, where every N-gon (quads included) is N sub-quads (`firstStep` = false, `faceMap` has
+// one entry per sub-quad).  A face is valid if it is not a hole, its indices are in range and its vertices are finite
+// (SubdivMesh::valid).
+static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std::vector<FaceMap>& faceMap, bool& firstStep,
+                                           const std::vector<D3>* values = nullptr) // values: refine these instead of the positions
 {
   const BufferView* vb = geom->view(RTC_BUFFER_TYPE_VERTEX, 0);
   const BufferView* ib = geom->view(RTC_BUFFER_TYPE_INDEX, 0);
@@ -350,15 +454,11 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
   }
   const RTCSubdivisionMode mode = geom->subdivMode.empty() ? RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY : geom->subdivMode[0];
 
-  cur.n = 1;
-  cur.P.resize(vb->count);
+  std::vector<D3> P(vb->count);
   for (size_t i = 0; i < vb->count; i++) {
     const float* p = (const float*)vb->at(i);
-    cur.P[i] = D3(p[0], p[1], p[2]);
+    P[i] = D3(p[0], p[1], p[2]);
   }
-  cur.pinned.assign(cur.P.size(), 0);
-  cur.bpin.assign(cur.P.size(), 0);
-
   std::vector<uint8_t> hole(fb->count, 0);
   if (const BufferView* hb = geom->view(RTC_BUFFER_TYPE_HOLE, 0))
     if (hb->valid())
@@ -367,38 +467,86 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
         if (f < hole.size()) hole[f] = 1;
       }
 
+  std::vector<std::vector<uint32_t>> faces;
+  std::vector<unsigned> facePrim;
+  bool allQuads = true;
   size_t cursor = 0;
   for (size_t f = 0; f < fb->count; f++) {
     const unsigned nv = *(const unsigned*)fb->at(f);
     if (cursor + nv > ib->count) RT_THROW(RTC_ERROR_INVALID_OPERATION, "face buffer overruns the index buffer");
-    if (nv != 4) RT_THROW(RTC_ERROR_INVALID_OPERATION, "only quad faces are supported by the MI355X tessellator yet");
-    uint32_t q[4];
+    if (nv < 3 || nv > 16) RT_THROW(RTC_ERROR_INVALID_OPERATION, "subdivision faces need 3..16 vertices (MAX_PATCH_VALENCE, catmullclark_coefficients.h:23)");
+    std::vector<uint32_t> q(nv);
     bool ok = !hole[f];
-    for (unsigned k = 0; k < 4; k++) {
+    for (unsigned k = 0; k < nv; k++) {
       q[k] = *(const unsigned*)ib->at(cursor + k);
-      if (q[k] >= cur.P.size()) ok = false;
-      else {
-        const D3& p = cur.P[q[k]];
-        if (!(std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z))) ok = false;
-      }
+      if (q[k] >= P.size()) ok = false;
+      else if (!(std::isfinite(P[q[k]].x) && std::isfinite(P[q[k]].y) && std::isfinite(P[q[k]].z))) ok = false;
     }
     cursor += nv;
     if (!ok) continue;
-    cur.grid.push_back({q[0], q[1], q[3], q[2]}); // row-major 2x2: (0,0)=v0 (1,0)=v1 (0,1)=v3 (1,1)=v2
+    if (nv != 4) allQuads = false;
+    faces.push_back(std::move(q));
     facePrim.push_back((unsigned)f);
   }
+  faceMap.clear();
+  firstStep = allQuads;
+  if (values) { // same topology and face validity, other per-vertex data (vertex attributes)
+    for (size_t i = 0; i < P.size(); i++) P[i] = i < values->size() ? (*values)[i] : D3();
+  }
+  if (allQuads) {
+    cur.n = 1;
+    cur.P = std::move(P);
+    cur.pinned.assign(cur.P.size(), 0);
+    cur.bpin.assign(cur.P.size(), 0);
+    cur.grid.clear();
+    for (size_t f = 0; f < faces.size(); f++) {
+      const std::vector<uint32_t>& q = faces[f];
+      cur.grid.push_back({q[0], q[1], q[3], q[2]}); // row-major 2x2: (0,0)=v0 (1,0)=v1 (0,1)=v3 (1,1)=v2
+      faceMap.push_back(FaceMap{facePrim[f], 4u, 0u});
+    }
+  } else {
+    refine_polygons(P, faces, mode, cur);
+    for (size_t f = 0; f < faces.size(); f++)
+      for (unsigned k = 0; k < faces[f].size(); k++) faceMap.push_back(FaceMap{facePrim[f], (unsigned)faces[f].size(), k});
+  }
   return mode;
+}
+
+// Vertex ids of the (n+1)^2 grid of one output patch.  Pure-quad meshes and sub-patches of non-quad faces: the face's
+// own grid.  A quad face of a mesh that also has non-quad faces exists as four sub-quads (k = corner number) of n
+// cells each; its grid at n cells per side takes every other point of them:
+//   k=0: (u,v) = (s/2, t/2)   k=1: (1 - t/2, s/2)   k=2: (1 - s/2, 1 - t/2)   k=3: (t/2, 1 - s/2)
+static void patch_vertex_ids(const Level& lv, const std::vector<FaceMap>& faceMap, size_t f, std::vector<uint32_t>& ids)
+{
+  const unsigned n = lv.n, w = n + 1;
+  if (!(faceMap[f].corners == 4 && lv.grid.size() == faceMap.size() && f + 3 < faceMap.size() && faceMap[f + 3].primID == faceMap[f].primID &&
+        faceMap[f + 1].sub == 1)) {
+    ids = lv.grid[f];
+    return;
+  }
+  ids.resize((size_t)w * w);
+  for (unsigned J = 0; J <= n; J++)
+    for (unsigned I = 0; I <= n; I++) {
+      const bool lowU = 2 * I <= n, lowV = 2 * J <= n;
+      unsigned k, si, ti; // sub-quad, local indices along its s and t
+      if (lowU && lowV) { k = 0; si = 2 * I; ti = 2 * J; }
+      else if (!lowU && lowV) { k = 1; si = 2 * J; ti = 2 * (n - I); }
+      else if (!lowU && !lowV) { k = 2; si = 2 * (n - I); ti = 2 * (n - J); }
+      else { k = 3; si = 2 * (n - J); ti = 2 * I; }
+      ids[(size_t)J * w + I] = lv.grid[f + k][(size_t)ti * w + si];
+    }
 }
 
 void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out)
 {
   if (L > 10) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "subdivision level too high");
   Level cur;
-  std::vector<unsigned> facePrim;
-  const RTCSubdivisionMode mode = build_base_level(geom, cur, facePrim);
-  if (cur.grid.empty()) return;
-
+  std::vector<FaceMap> faceMap;
   bool first = true;
+  const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first);
+  if (cur.grid.empty()) return;
+  const bool mixed = !first; // faces of other arity than 4 exist: the base level already is one Catmull-Clark step deep
+
   for (unsigned l = 0; l < L; l++) {
     Refiner r(cur, mode, first);
     r.accumulate();
@@ -425,13 +573,11 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
   const bool noBoundary = mode == RTC_SUBDIVISION_MODE_NO_BOUNDARY;
   out.reserve(out.size() + cur.grid.size());
   std::vector<float> gu(N), gv(N), nx, ny, nz;
-  for (unsigned j = 0; j <= n; j++)
-    for (unsigned i = 0; i <= n; i++) {
-      gu[(size_t)j * w + i] = (float)i / (float)n; // gridUVTessellator: (x0+i) * rcp(n), exact for n = 2^L
-      gv[(size_t)j * w + i] = (float)j / (float)n;
-    }
+  std::vector<uint32_t> g;
   for (size_t f = 0; f < cur.grid.size(); f++) {
-    const std::vector<uint32_t>& g = cur.grid[f];
+    const FaceMap& fm = faceMap[f];
+    if (mixed && fm.corners == 4 && fm.sub != 0) continue; // sub-quads 1..3 of a quad face are consumed with sub-quad 0
+    patch_vertex_ids(cur, faceMap, f, g);
     if (noBoundary) { // RTC_SUBDIVISION_MODE_NO_BOUNDARY: patches touching the border are not rendered
       bool touches = false;
       for (size_t k = 0; k < N && !touches; k++) touches = fin.acc[g[k]].nb != 0;
@@ -440,8 +586,12 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
     out.emplace_back();
     PatchGrid& pg = out.back();
     pg.geomID = geomID;
-    pg.primID = facePrim[f];
+    pg.primID = fm.primID;
     pg.n = n;
+    if (fm.corners != 4) { // sub-patch number in the integer part of uv, patch_eval_grid.h:241-254
+      pg.u0 = 2.0f * (float)(fm.sub & 3) + 0.5f;
+      pg.v0 = 2.0f * (float)((fm.sub >> 2) & 3) + 0.5f;
+    }
     pg.x.resize(N); pg.y.resize(N); pg.z.resize(N);
     for (size_t k = 0; k < N; k++) {
       const D3& p = limit[g[k]];
@@ -450,6 +600,11 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
     if (displ) {
       pg.bx = pg.x; pg.by = pg.y; pg.bz = pg.z;
       nx.resize(N); ny.resize(N); nz.resize(N);
+      for (unsigned j = 0; j <= n; j++)
+        for (unsigned i = 0; i <= n; i++) {
+          gu[(size_t)j * w + i] = pg.u0 + (float)i / (float)n; // gridUVTessellator: (x0+i) * rcp(n), exact for n = 2^L
+          gv[(size_t)j * w + i] = pg.v0 + (float)j / (float)n;
+        }
       for (size_t k = 0; k < N; k++) {
         D3 nn = ne->normal(g[k]);
         const double len2 = dot(nn, nn);
@@ -470,7 +625,6 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
     }
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // rtcInterpolate
@@ -506,8 +660,10 @@ struct InterpChannels
 };
 struct SubdivInterpCache
 {
-  unsigned n = 8; // sub-faces per face side (2^K)
-  std::vector<int> primToFace;
+  unsigned n = 8; // sub-faces per base-face side (2^K)
+  bool mixed = false;             // the mesh has faces that are not quads: base faces are the sub-quads of one generic step
+  std::vector<int> primToFace;    // primID -> first base face (-1: invalid face)
+  std::vector<unsigned> primCorners; // primID -> number of corners
   std::vector<std::vector<uint32_t>> grid;   // level-K vertex ids per face
   std::vector<uint32_t> vqStart, vqList;     // vertex -> incident sub-faces (id = face*n*n + j*n + i)
   std::vector<uint8_t> irregular;            // vertex is on a boundary, pinned, or has valence != 4
@@ -516,9 +672,8 @@ struct SubdivInterpCache
 };
 static const unsigned INTERP_LEVELS = 3;
 
-static void refine_to_interp_level(Level& cur, RTCSubdivisionMode mode, std::vector<D3>* limit, std::vector<uint8_t>* irregular)
+static void refine_to_interp_level(Level& cur, RTCSubdivisionMode mode, bool first, std::vector<D3>* limit, std::vector<uint8_t>* irregular)
 {
-  bool first = true;
   for (unsigned l = 0; l < INTERP_LEVELS; l++) {
     Refiner r(cur, mode, first);
     r.accumulate();
@@ -564,12 +719,18 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
     if (!cache) { // topology part, once per commit of the geometry
       cache = std::make_shared<SubdivInterpCache>();
       Level cur;
-      std::vector<unsigned> facePrim;
-      const RTCSubdivisionMode mode = build_base_level(geom, cur, facePrim);
+      std::vector<FaceMap> faceMap;
+      bool first = true;
+      const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first);
+      cache->mixed = !first;
       const BufferView* fb = geom->view(RTC_BUFFER_TYPE_FACE, 0);
       cache->primToFace.assign(fb->count, -1);
-      for (size_t f = 0; f < facePrim.size(); f++) cache->primToFace[facePrim[f]] = (int)f;
-      refine_to_interp_level(cur, mode, nullptr, &cache->irregular);
+      cache->primCorners.assign(fb->count, 0);
+      for (size_t f = faceMap.size(); f-- > 0;) { // descending: the entry that stays is the first base face of the prim
+        cache->primToFace[faceMap[f].primID] = (int)f;
+        cache->primCorners[faceMap[f].primID] = faceMap[f].corners;
+      }
+      refine_to_interp_level(cur, mode, first, nullptr, &cache->irregular);
       cache->n = cur.n;
       cache->grid = cur.grid;
       const unsigned n = cur.n, w = n + 1;
@@ -597,21 +758,22 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
     std::lock_guard<std::mutex> g(cache->mutex);
     std::vector<InterpChannels>& c = cache->buffers[std::make_pair((int)args->bufferType, args->bufferSlot)];
     if (c.size() < groups) { // refine the channels not seen before
-      Level base;
-      std::vector<unsigned> facePrim;
-      const RTCSubdivisionMode mode = build_base_level(geom, base, facePrim);
       const size_t floatsPerVertex = src->stride / sizeof(float);
       for (unsigned gi = (unsigned)c.size(); gi < groups; gi++) {
-        InterpChannels ch;
-        ch.lvl = base;
-        for (size_t v = 0; v < base.P.size() && v < src->count; v++) {
+        // the topology comes from the vertex buffer (face validity), the values from three channels of `src`
+        std::vector<D3> values(src->count);
+        for (size_t v = 0; v < src->count; v++) {
           const float* p = (const float*)src->at(v);
           double val[3] = {0.0, 0.0, 0.0};
           for (unsigned k = 0; k < 3; k++)
             if (3 * gi + k < args->valueCount && 3 * gi + k < floatsPerVertex) val[k] = p[3 * gi + k];
-          ch.lvl.P[v] = D3(val[0], val[1], val[2]);
+          values[v] = D3(val[0], val[1], val[2]);
         }
-        refine_to_interp_level(ch.lvl, mode, &ch.limit, nullptr);
+        InterpChannels ch;
+        std::vector<FaceMap> faceMap;
+        bool first = true;
+        const RTCSubdivisionMode mode = build_base_level(geom, ch.lvl, faceMap, first, &values);
+        refine_to_interp_level(ch.lvl, mode, first, &ch.limit, nullptr);
         c.push_back(std::move(ch));
       }
     }
@@ -620,10 +782,30 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
 
   if (args->primID >= cache->primToFace.size() || cache->primToFace[args->primID] < 0)
     RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: invalid primID");
-  const size_t f = (size_t)cache->primToFace[args->primID];
+  // base face and local parameters (ls, lt) in [0,1]^2; d(ls,lt)/d(u,v) = [[jsu, jsv], [jtu, jtv]]
+  size_t f = (size_t)cache->primToFace[args->primID];
+  double ls = args->u, lt = args->v, jsu = 1.0, jsv = 0.0, jtu = 0.0, jtv = 1.0;
+  if (cache->mixed) {
+    if (cache->primCorners[args->primID] != 4) { // PatchEval::eval_general, patch_eval.h:71-77
+      const double hu = 0.5 * args->u, hv = 0.5 * args->v;
+      const unsigned l = (unsigned)std::max(0.0, floor(hu)), h = (unsigned)std::max(0.0, floor(hv));
+      const unsigned sub = 4 * h + l;
+      if (sub >= cache->primCorners[args->primID]) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: uv does not address a sub-patch of this face");
+      f += sub;
+      ls = std::min(1.0, std::max(0.0, 2.0 * (hu - floor(hu)) - 0.5));
+      lt = std::min(1.0, std::max(0.0, 2.0 * (hv - floor(hv)) - 0.5));
+    } else { // quad face held as four corner sub-quads (see patch_vertex_ids)
+      const double u = args->u, v = args->v;
+      const bool lowU = u <= 0.5, lowV = v <= 0.5;
+      if (lowU && lowV) { ls = 2 * u; lt = 2 * v; jsu = 2; jtv = 2; }
+      else if (!lowU && lowV) { f += 1; ls = 2 * v; lt = 2 * (1 - u); jsu = 0; jsv = 2; jtu = -2; jtv = 0; }
+      else if (!lowU && !lowV) { f += 2; ls = 2 * (1 - u); lt = 2 * (1 - v); jsu = -2; jtv = -2; }
+      else { f += 3; ls = 2 * (1 - v); lt = 2 * u; jsu = 0; jsv = -2; jtu = 2; jtv = 0; }
+    }
+  }
   const unsigned n = cache->n, w = n + 1;
   const std::vector<uint32_t>& g = cache->grid[f];
-  const double x = (double)args->u * n, y = (double)args->v * n;
+  const double x = ls * n, y = lt * n;
   const unsigned i = (unsigned)std::min<double>(std::max(0.0, floor(x)), n - 1), j = (unsigned)std::min<double>(std::max(0.0, floor(y)), n - 1);
   const double s = x - i, t = y - j;
   const uint32_t q = (uint32_t)(f * n * n + (size_t)j * n + i);
@@ -699,9 +881,14 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
       Pv = (L01 - L00) * (1 - s) + (L11 - L10) * s;
       Puv = (L11 - L10) - (L01 - L00);
     }
-    const double vP[3] = {P.x, P.y, P.z}, vu[3] = {Pu.x * sc, Pu.y * sc, Pu.z * sc}, vv[3] = {Pv.x * sc, Pv.y * sc, Pv.z * sc};
-    const double vuu[3] = {Puu.x * sc * sc, Puu.y * sc * sc, Puu.z * sc * sc}, vvv[3] = {Pvv.x * sc * sc, Pvv.y * sc * sc, Pvv.z * sc * sc};
-    const double vuv[3] = {Puv.x * sc * sc, Puv.y * sc * sc, Puv.z * sc * sc};
+    // derivatives w.r.t. the base face's (ls, lt), then the chain rule to the caller's (u, v) (the map is affine)
+    const D3 Ds = Pu * sc, Dt = Pv * sc, Dss = Puu * (sc * sc), Dtt = Pvv * (sc * sc), Dst = Puv * (sc * sc);
+    const D3 Du = Ds * jsu + Dt * jtu, Dv = Ds * jsv + Dt * jtv;
+    const D3 Duu = Dss * (jsu * jsu) + Dst * (2.0 * jsu * jtu) + Dtt * (jtu * jtu);
+    const D3 Dvv = Dss * (jsv * jsv) + Dst * (2.0 * jsv * jtv) + Dtt * (jtv * jtv);
+    const D3 Duv = Dss * (jsu * jsv) + Dst * (jsu * jtv + jsv * jtu) + Dtt * (jtu * jtv);
+    const double vP[3] = {P.x, P.y, P.z}, vu[3] = {Du.x, Du.y, Du.z}, vv[3] = {Dv.x, Dv.y, Dv.z};
+    const double vuu[3] = {Duu.x, Duu.y, Duu.z}, vvv[3] = {Dvv.x, Dvv.y, Dvv.z}, vuv[3] = {Duv.x, Duv.y, Duv.z};
     for (unsigned k = 0; k < 3 && 3 * gi + k < args->valueCount; k++) {
       const unsigned o = 3 * gi + k;
       if (args->P) args->P[o] = (float)vP[k];

@@ -20,7 +20,10 @@ struct PatchGrid
   unsigned n = 0;
   std::vector<float> x, y, z;       // displaced positions (what evalGrid(..., applyDisplacement=true) returns)
   std::vector<float> bx, by, bz;    // undisplaced limit positions; empty when the geometry has no displacement
-  // patch uv of grid point (i,j) is (i/n, j/n): quads have uv corners (0,0),(1,0),(1,1),(0,1)
+  // patch uv of grid point (i,j) is (u0 + i/n, v0 + j/n).  Quads: u0 = v0 = 0, uv corners (0,0),(1,0),(1,1),(0,1).
+  // Sub-patch k of a non-quad face: (u0,v0) = (2*(k&3) + 0.5, 2*((k>>2)&3) + 0.5), the reference's encoding of the
+  // sub-patch number in the integer part of uv (patch_eval_grid.h:241-254).
+  float u0 = 0.f, v0 = 0.f;
   float px(size_t k, bool base) const { return base && !bx.empty() ? bx[k] : x[k]; }
   float py(size_t k, bool base) const { return base && !by.empty() ? by[k] : y[k]; }
   float pz(size_t k, bool base) const { return base && !bz.empty() ? bz[k] : z[k]; }

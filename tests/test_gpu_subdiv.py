@@ -185,3 +185,40 @@ def test_subdiv_modes_and_errors(rtc):
     assert dev.error() == rtc.RTC_ERROR_INVALID_ARGUMENT
     sc.release()
     dev.release()
+
+
+@pytest.mark.parametrize("accel", list(ACCELS))
+def test_non_quad_faces_parity(rtc, po, accel):
+    """A closed prism of 2 triangles + 3 quads: triangles become three sub-patches each, with the sub-patch number in the
+    integer part of uv (patch_eval_grid.h:241-254).  GPU vs oracle on the exported records, plus the uv windows of the hits."""
+    V = np.array([[0, 0, 0], [2, 0, 0], [1, 1.7, 0], [0, 0, 3], [2, 0, 3], [1, 1.7, 3]], np.float32)
+    F = [(0, 2, 1), (3, 4, 5), (0, 1, 4, 3), (1, 2, 5, 4), (2, 0, 3, 5)]
+    fs = np.array([len(f) for f in F], np.uint32)
+    fi = np.concatenate([np.array(f, np.uint32) for f in F])
+    dev, sc = _build(rtc, accel, V, fs, fi, 4, 2)
+    st = sc.stats()
+    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 2, qnodes=sc.accel_data(0), root=sc.accel_root())
+    else:
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 2)
+    n = 200_000
+    want = po.make_random_rays(n, V.min(0) - 0.5, V.max(0) + 0.5, seed=8)
+    got = want.copy()
+    orc.intersect1M(want, nthreads=8)
+    sc.intersect1M(got)
+    nh = compare_hits(got, want, what=f"prism {accel}")
+    assert nh > 0.2 * n
+    hit = got["geomID"] != INVALID
+    tri = hit & (got["primID"] < 2)
+    quad = hit & (got["primID"] >= 2)
+    assert tri.sum() > 1000 and quad.sum() > 1000 and got["primID"][hit].max() == 4
+    eps = 1e-3
+    assert (got["u"][quad] >= -eps).all() and (got["u"][quad] <= 1 + eps).all() and (got["v"][quad] >= -eps).all() and (got["v"][quad] <= 1 + eps).all()
+    u, v = got["u"][tri], got["v"][tri]
+    sub = np.floor(0.5 * u).astype(int)  # PatchEval::eval_general, patch_eval.h:73-75
+    assert set(np.unique(sub)) == {0, 1, 2}
+    lu = u - 2 * sub - 0.5
+    assert (lu >= -eps).all() and (lu <= 1 + eps).all() and (v >= 0.5 - eps).all() and (v <= 1.5 + eps).all()
+    orc.free()
+    sc.release()
+    dev.release()
