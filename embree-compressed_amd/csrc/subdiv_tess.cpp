@@ -30,6 +30,10 @@ struct Acc
   D3 sumN; // sum of edge neighbours
   D3 sumB; // sum of neighbours along boundary edges
   uint32_t nf = 0, ne = 0, nb = 0;
+  // semi-sharp creases on interior edges (crease weight > 0): count, sum of the far endpoints, the first two weights
+  D3 sumC;
+  uint32_t nc = 0;
+  float cw[2] = {0.f, 0.f};
 };
 
 struct BorderEdge
@@ -38,6 +42,7 @@ struct BorderEdge
   uint32_t count;
   uint32_t a, b;
   D3 sumFp;
+  float crease = 0.f; // semi-sharp weight of an interior edge (0: smooth)
 };
 
 struct Level
@@ -47,6 +52,12 @@ struct Level
   std::vector<std::vector<uint32_t>> grid;  // per face: (n+1)^2 vertex ids, row-major [j][i]
   std::vector<uint8_t> pinned;              // per vertex: position is fixed under refinement
   std::vector<uint8_t> bpin;                // per vertex: lies on a pinned (linear) boundary
+  // creases (rtcore_geometry.h crease buffers; rules of CatmullClark1RingT::subdivide, catmullclark_ring.h:213-315):
+  // weight per creased interior edge (key = edge_key of its endpoints at THIS level, weights > 0 only) and per vertex
+  // (empty = no vertex creases).  Mesh boundaries are not stored here: they are creases of infinite weight by rule.
+  std::unordered_map<uint64_t, float> crease;
+  std::vector<float> vcrease;
+  float vertex_crease(uint32_t v) const { return v < vcrease.size() ? vcrease[v] : 0.f; }
 };
 
 inline uint64_t edge_key(uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
@@ -98,14 +109,28 @@ struct Refiner
       }
     }
     for (auto& kv : border) {
-      const BorderEdge& e = kv.second;
+      BorderEdge& e = kv.second;
       link(e.a, e.b);
       if (e.count != 2) { // mesh boundary (count 1) or non-manifold edge
         acc[e.a].sumB += in.P[e.b]; acc[e.a].nb++;
         acc[e.b].sumB += in.P[e.a]; acc[e.b].nb++;
+      } else if (!in.crease.empty()) {
+        auto it = in.crease.find(kv.first);
+        if (it != in.crease.end() && it->second > 0.f) {
+          e.crease = it->second;
+          for (int side = 0; side < 2; side++) {
+            Acc& a = acc[side ? e.b : e.a];
+            a.sumC += in.P[side ? e.a : e.b];
+            if (a.nc < 2) a.cw[a.nc] = e.crease;
+            a.nc++;
+          }
+        }
       }
     }
   }
+
+  static D3 lerp3(const D3& a, const D3& b, double t) { return a * (1.0 - t) + b * t; }
+  bool creased(uint32_t v) const { return acc[v].nc != 0 || in.vertex_crease(v) > 0.f; }
 
   void link(uint32_t a, uint32_t b)
   {
@@ -155,11 +180,22 @@ struct Refiner
     const Acc& a = acc[v];
     const D3& p = in.P[v];
     if (pinned[v] || a.ne == 0) return p;
+    D3 smooth;
     if (a.nb == 0) { // smooth interior vertex of valence n
       const double n = (double)a.ne;
-      return a.sumF * (1.0 / (n * n)) + a.sumN * (1.0 / (n * n)) + p * ((n - 2.0) / n);
-    }
-    return p * 0.75 + a.sumB * 0.125; // smooth boundary: cubic B-spline curve rule
+      smooth = a.sumF * (1.0 / (n * n)) + a.sumN * (1.0 / (n * n)) + p * ((n - 2.0) / n);
+    } else
+      smooth = p * 0.75 + a.sumB * 0.125; // smooth boundary: cubic B-spline curve rule (= crease rule with the two border edges)
+    if (!creased(v)) return smooth;
+    // vertex crease, then edge creases; border edges count as creases of infinite weight (catmullclark_ring.h:276-314)
+    const float vw = in.vertex_crease(v);
+    if (vw > 0.f) return vw >= 1.f ? p : lerp3(smooth, p, vw);
+    const uint32_t sharp = a.nb + a.nc;
+    if (sharp <= 1) return smooth; // dart
+    if (sharp > 2) return p;       // corner
+    const D3 crease = p * 0.75 + a.sumC * 0.125; // nb == 0, nc == 2
+    const double blend = 0.5 * ((double)a.cw[0] + (double)a.cw[1]);
+    return blend >= 1.0 ? crease : lerp3(smooth, crease, blend);
   }
 
   D3 limit_point(uint32_t v, const std::vector<uint8_t>& pinned) const
@@ -167,12 +203,25 @@ struct Refiner
     const Acc& a = acc[v];
     const D3& p = in.P[v];
     if (pinned[v] || a.ne == 0) return p;
+    D3 smooth;
     if (a.nb == 0) {
       const double n = (double)a.ne;
       const D3 sumD = a.sumF * 4.0 - p * n - a.sumN * 2.0; // diagonal neighbours, from F = (V+N_i+N_i+1+D_i)/4
-      return (p * (n * n) + a.sumN * 4.0 + sumD) * (1.0 / (n * (n + 5.0)));
-    }
-    return (p * 4.0 + a.sumB) * (1.0 / 6.0);
+      smooth = (p * (n * n) + a.sumN * 4.0 + sumD) * (1.0 / (n * (n + 5.0)));
+    } else
+      smooth = (p * 4.0 + a.sumB) * (1.0 / 6.0);
+    if (!creased(v)) return smooth;
+    // Creases that are still alive at the tessellation level: weights >= 1 are treated as sharp for good, fractional
+    // rests blend the sharp and the smooth limit.  (The reference subdivides on adaptively until every weight has
+    // decayed, patch.h:40-41; exact here whenever the weights are integers <= the level or much larger than it.)
+    const float vw = in.vertex_crease(v);
+    if (vw > 0.f) return vw >= 1.f ? p : lerp3(smooth, p, vw);
+    const uint32_t sharp = a.nb + a.nc;
+    if (sharp <= 1) return smooth;
+    if (sharp > 2) return p;
+    const D3 crease = (p * 4.0 + a.sumC) * (1.0 / 6.0);
+    const double blend = std::min(1.0, 0.5 * ((double)a.cw[0] + (double)a.cw[1]));
+    return lerp3(smooth, crease, blend);
   }
 
   void refine(Level& out)
@@ -191,11 +240,36 @@ struct Refiner
     out.bpin.resize(out.P.size(), 0);
     for (uint32_t v = 0; v < nV; v++) out.P[v] = vertex_point(v, out.pinned);
     const bool pinAll = mode == RTC_SUBDIVISION_MODE_PIN_ALL;
+    out.crease.clear();
+    out.vcrease.clear();
+    if (!in.vcrease.empty()) {
+      out.vcrease.assign(out.P.size(), 0.f);
+      for (size_t v = 0; v < in.vcrease.size() && v < nV; v++) out.vcrease[v] = std::max(in.vcrease[v] - 1.f, 0.f);
+    }
+    // weight of the half of a creased edge next to endpoint v (catmullclark_ring.h:244,299-302): Chaikin's rule where
+    // exactly two creases meet at a vertex without vertex crease, otherwise weight - 1
+    auto child_weight = [&](uint32_t v, float wgt) -> float {
+      const Acc& a = acc[v];
+      if (in.vertex_crease(v) <= 0.f && a.nb == 0 && a.nc == 2) {
+        const float other = a.cw[0] + a.cw[1] - wgt;
+        return std::max(0.25f * (3.0f * wgt + other) - 1.0f, 0.0f);
+      }
+      return std::max(wgt - 1.0f, 0.0f);
+    };
     for (auto& kv : border) {
       const BorderEdge& e = kv.second;
       const size_t id = nV + e.idx;
-      if (e.count == 2 && !pinAll) out.P[id] = (in.P[e.a] + in.P[e.b] + e.sumFp) * 0.25;
-      else {
+      if (e.count == 2 && !pinAll) {
+        const D3 smoothE = (in.P[e.a] + in.P[e.b] + e.sumFp) * 0.25;
+        if (e.crease <= 0.f) out.P[id] = smoothE;
+        else {
+          const D3 mid = (in.P[e.a] + in.P[e.b]) * 0.5;
+          out.P[id] = e.crease >= 1.f ? mid : lerp3(smoothE, mid, e.crease);
+          const float wa = child_weight(e.a, e.crease), wb = child_weight(e.b, e.crease);
+          if (wa > 0.f) out.crease[edge_key(e.a, (uint32_t)id)] = wa;
+          if (wb > 0.f) out.crease[edge_key(e.b, (uint32_t)id)] = wb;
+        }
+      } else {
         out.P[id] = (in.P[e.a] + in.P[e.b]) * 0.5;
         if (out.bpin[e.a] && out.bpin[e.b]) { out.pinned[id] = 1; out.bpin[id] = 1; } // linear boundary stays linear
       }
@@ -300,7 +374,7 @@ struct NormalEval
     const Acc& a = R.acc[v];
     const D3& P = lv.P[v];
     D3 ta, tb;
-    if (a.nb == 0 && a.ne == nq && nq >= 3) {
+    if (a.nb == 0 && a.ne == nq && nq >= 3 && !R.creased(v)) {
       // limit tangents of an interior vertex of valence n (Halstead et al. 1993): cos / sin combinations of the ring
       const double n = (double)nq, two_pi_n = 2.0 * M_PI / n;
       const double An = 1.0 + cos(two_pi_n) + cos(M_PI / n) * sqrt(2.0 * (9.0 + cos(two_pi_n)));
@@ -310,7 +384,7 @@ struct NormalEval
         ta += lv.P[c.next] * (An * c0) + lv.P[c.diag] * (c0 + c1);
         tb += lv.P[c.next] * (An * s0) + lv.P[c.diag] * (s0 + s1);
       }
-    } else if (a.nb == 2 && nq == 2) {
+    } else if (a.nb == 2 && nq == 2 && !R.creased(v)) {
       // regular boundary vertex: mirror the interior row across the boundary (phantom vertices of the cubic
       // B-spline end condition) and apply the regular stencil
       const Corner& q0 = corners[order[0]];
@@ -347,12 +421,15 @@ struct FaceMap
 // sub-quad k = (vertex point of corner k, edge point of edge k -> k+1, face point, edge point of edge k-1 -> k), the
 // vertex order of the reference's sub-patches (GeneralCatmullClarkPatch::subdivide, catmullclark_patch.h:442-483:
 // ring[0] = corner, ring[1] = next edge, ring[2] = centre, ring[3] = previous edge).  Same rules as Refiner::refine.
-static void refine_polygons(const std::vector<D3>& P, const std::vector<std::vector<uint32_t>>& faces, RTCSubdivisionMode mode, Level& out)
+static void refine_polygons(const std::vector<D3>& P, const std::vector<std::vector<uint32_t>>& faces, RTCSubdivisionMode mode,
+                            const std::unordered_map<uint64_t, float>& crease, const std::vector<float>& vcrease, Level& out)
 {
+  auto vertex_crease = [&](uint32_t v) { return v < vcrease.size() ? vcrease[v] : 0.f; };
+  auto lerp3 = [](const D3& a, const D3& b, double t) { return a * (1.0 - t) + b * t; };
   const size_t nV = P.size(), nF = faces.size();
   std::vector<Acc> acc(nV);
   std::vector<D3> fp(nF);
-  struct Edge { uint32_t idx, count, a, b; D3 sumFp; };
+  struct Edge { uint32_t idx, count, a, b; D3 sumFp; float crease; };
   std::unordered_map<uint64_t, Edge> edges;
   edges.reserve(nF * 4);
   for (size_t f = 0; f < nF; f++) {
@@ -365,17 +442,28 @@ static void refine_polygons(const std::vector<D3>& P, const std::vector<std::vec
       acc[q[k]].nf++;
       const uint32_t a = q[k], b = q[(k + 1) % q.size()];
       auto it = edges.find(edge_key(a, b));
-      if (it == edges.end()) edges.emplace(edge_key(a, b), Edge{(uint32_t)edges.size(), 1u, a, b, fp[f]});
+      if (it == edges.end()) edges.emplace(edge_key(a, b), Edge{(uint32_t)edges.size(), 1u, a, b, fp[f], 0.f});
       else { it->second.count++; it->second.sumFp += fp[f]; }
     }
   }
   for (auto& kv : edges) {
-    const Edge& e = kv.second;
+    Edge& e = kv.second;
     acc[e.a].sumN += P[e.b]; acc[e.a].ne++;
     acc[e.b].sumN += P[e.a]; acc[e.b].ne++;
     if (e.count != 2) {
       acc[e.a].sumB += P[e.b]; acc[e.a].nb++;
       acc[e.b].sumB += P[e.a]; acc[e.b].nb++;
+    } else {
+      auto it = crease.find(kv.first);
+      if (it != crease.end() && it->second > 0.f) {
+        e.crease = it->second;
+        for (int side = 0; side < 2; side++) {
+          Acc& a = acc[side ? e.b : e.a];
+          a.sumC += P[side ? e.a : e.b];
+          if (a.nc < 2) a.cw[a.nc] = e.crease;
+          a.nc++;
+        }
+      }
     }
   }
   // boundary classification exactly as Refiner::classify on the first level
@@ -399,20 +487,50 @@ static void refine_polygons(const std::vector<D3>& P, const std::vector<std::vec
     }
   }
   const bool pinAll = mode == RTC_SUBDIVISION_MODE_PIN_ALL;
-  for (size_t v = 0; v < nV; v++) {
-    const Acc& a = acc[v];
-    if (out.pinned[v] || a.ne == 0) out.P[v] = P[v];
-    else if (a.nb == 0) {
-      const double n = (double)a.ne;
-      out.P[v] = a.sumF * (1.0 / (n * n)) + a.sumN * (1.0 / (n * n)) + P[v] * ((n - 2.0) / n);
-    } else
-      out.P[v] = P[v] * 0.75 + a.sumB * 0.125;
+  if (!vcrease.empty()) {
+    out.vcrease.assign(out.P.size(), 0.f);
+    for (size_t v = 0; v < vcrease.size() && v < nV; v++) out.vcrease[v] = std::max(vcrease[v] - 1.f, 0.f);
   }
+  for (size_t v = 0; v < nV; v++) { // same rules as Refiner::vertex_point
+    const Acc& a = acc[v];
+    if (out.pinned[v] || a.ne == 0) { out.P[v] = P[v]; continue; }
+    D3 smooth;
+    if (a.nb == 0) {
+      const double n = (double)a.ne;
+      smooth = a.sumF * (1.0 / (n * n)) + a.sumN * (1.0 / (n * n)) + P[v] * ((n - 2.0) / n);
+    } else
+      smooth = P[v] * 0.75 + a.sumB * 0.125;
+    const float vw = vertex_crease((uint32_t)v);
+    const uint32_t sharp = a.nb + a.nc;
+    if (a.nc == 0 && vw <= 0.f) out.P[v] = smooth;
+    else if (vw > 0.f) out.P[v] = vw >= 1.f ? P[v] : lerp3(smooth, P[v], vw);
+    else if (sharp <= 1) out.P[v] = smooth;
+    else if (sharp > 2) out.P[v] = P[v];
+    else {
+      const D3 cr = P[v] * 0.75 + a.sumC * 0.125;
+      const double blend = 0.5 * ((double)a.cw[0] + (double)a.cw[1]);
+      out.P[v] = blend >= 1.0 ? cr : lerp3(smooth, cr, blend);
+    }
+  }
+  auto child_weight = [&](uint32_t v, float wgt) -> float {
+    const Acc& a = acc[v];
+    if (vertex_crease(v) <= 0.f && a.nb == 0 && a.nc == 2) return std::max(0.25f * (3.0f * wgt + (a.cw[0] + a.cw[1] - wgt)) - 1.0f, 0.0f);
+    return std::max(wgt - 1.0f, 0.0f);
+  };
   for (auto& kv : edges) {
     const Edge& e = kv.second;
     const size_t id = nV + e.idx;
-    if (e.count == 2 && !pinAll) out.P[id] = (P[e.a] + P[e.b] + e.sumFp) * 0.25;
-    else {
+    if (e.count == 2 && !pinAll) {
+      const D3 smoothE = (P[e.a] + P[e.b] + e.sumFp) * 0.25;
+      if (e.crease <= 0.f) out.P[id] = smoothE;
+      else {
+        const D3 mid = (P[e.a] + P[e.b]) * 0.5;
+        out.P[id] = e.crease >= 1.f ? mid : lerp3(smoothE, mid, e.crease);
+        const float wa = child_weight(e.a, e.crease), wb = child_weight(e.b, e.crease);
+        if (wa > 0.f) out.crease[edge_key(e.a, (uint32_t)id)] = wa;
+        if (wb > 0.f) out.crease[edge_key(e.b, (uint32_t)id)] = wb;
+      }
+    } else {
       out.P[id] = (P[e.a] + P[e.b]) * 0.5;
       if (out.bpin[e.a] && out.bpin[e.b]) { out.pinned[id] = 1; out.bpin[id] = 1; }
     }
@@ -448,9 +566,31 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
   const BufferView* fb = geom->view(RTC_BUFFER_TYPE_FACE, 0);
   if (!vb || !vb->valid() || !ib || !ib->valid() || !fb || !fb->valid())
     RT_THROW(RTC_ERROR_INVALID_OPERATION, "subdivision geometry needs vertex, index and face buffers");
-  for (RTCBufferType t : {RTC_BUFFER_TYPE_EDGE_CREASE_INDEX, RTC_BUFFER_TYPE_VERTEX_CREASE_INDEX}) {
-    const BufferView* c = geom->view(t, 0);
-    if (c && c->valid() && c->count) RT_THROW(RTC_ERROR_INVALID_OPERATION, "crease buffers are not supported by the MI355X tessellator yet");
+  // crease buffers (SubdivMesh::edgeCreaseMap / vertexCreaseMap, scene_subdiv_mesh.cpp:150-190): pairs of vertex indices
+  // with a weight each, vertex indices with a weight each
+  std::unordered_map<uint64_t, float> crease;
+  std::vector<float> vcrease;
+  {
+    const BufferView* ei = geom->view(RTC_BUFFER_TYPE_EDGE_CREASE_INDEX, 0);
+    const BufferView* ew = geom->view(RTC_BUFFER_TYPE_EDGE_CREASE_WEIGHT, 0);
+    if (ei && ei->valid() && ei->count) {
+      if (!ew || !ew->valid() || ew->count < ei->count) RT_THROW(RTC_ERROR_INVALID_OPERATION, "edge crease index buffer without matching weight buffer");
+      for (size_t i = 0; i < ei->count; i++) {
+        const unsigned* e = (const unsigned*)ei->at(i);
+        const float wgt = *(const float*)ew->at(i);
+        if (e[0] != e[1] && e[0] < vb->count && e[1] < vb->count && wgt > 0.f) crease[edge_key(e[0], e[1])] = wgt;
+      }
+    }
+    const BufferView* vi = geom->view(RTC_BUFFER_TYPE_VERTEX_CREASE_INDEX, 0);
+    const BufferView* vw = geom->view(RTC_BUFFER_TYPE_VERTEX_CREASE_WEIGHT, 0);
+    if (vi && vi->valid() && vi->count) {
+      if (!vw || !vw->valid() || vw->count < vi->count) RT_THROW(RTC_ERROR_INVALID_OPERATION, "vertex crease index buffer without matching weight buffer");
+      vcrease.assign(vb->count, 0.f);
+      for (size_t i = 0; i < vi->count; i++) {
+        const unsigned v = *(const unsigned*)vi->at(i);
+        if (v < vb->count) vcrease[v] = std::max(0.f, *(const float*)vw->at(i));
+      }
+    }
   }
   const RTCSubdivisionMode mode = geom->subdivMode.empty() ? RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY : geom->subdivMode[0];
 
@@ -498,6 +638,8 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
     cur.P = std::move(P);
     cur.pinned.assign(cur.P.size(), 0);
     cur.bpin.assign(cur.P.size(), 0);
+    cur.crease = crease;
+    cur.vcrease = vcrease;
     cur.grid.clear();
     for (size_t f = 0; f < faces.size(); f++) {
       const std::vector<uint32_t>& q = faces[f];
@@ -505,7 +647,7 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
       faceMap.push_back(FaceMap{facePrim[f], 4u, 0u});
     }
   } else {
-    refine_polygons(P, faces, mode, cur);
+    refine_polygons(P, faces, mode, crease, vcrease, cur);
     for (size_t f = 0; f < faces.size(); f++)
       for (unsigned k = 0; k < faces[f].size(); k++) faceMap.push_back(FaceMap{facePrim[f], (unsigned)faces[f].size(), k});
   }
@@ -692,7 +834,7 @@ static void refine_to_interp_level(Level& cur, RTCSubdivisionMode mode, bool fir
   }
   if (irregular) {
     irregular->resize(cur.P.size());
-    for (size_t v = 0; v < cur.P.size(); v++) (*irregular)[v] = (fin.acc[v].nb != 0 || pinned[v] || fin.acc[v].nf != 4 || fin.acc[v].ne != 4) ? 1 : 0;
+    for (size_t v = 0; v < cur.P.size(); v++) (*irregular)[v] = (fin.acc[v].nb != 0 || pinned[v] || fin.acc[v].nf != 4 || fin.acc[v].ne != 4 || fin.creased((uint32_t)v)) ? 1 : 0;
   }
 }
 

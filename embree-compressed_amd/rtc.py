@@ -23,6 +23,10 @@ RTC_BUFFER_TYPE_VERTEX = 1
 RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE = 2
 RTC_BUFFER_TYPE_FACE = 16
 RTC_BUFFER_TYPE_LEVEL = 17
+RTC_BUFFER_TYPE_EDGE_CREASE_INDEX = 18
+RTC_BUFFER_TYPE_EDGE_CREASE_WEIGHT = 19
+RTC_BUFFER_TYPE_VERTEX_CREASE_INDEX = 20
+RTC_BUFFER_TYPE_VERTEX_CREASE_WEIGHT = 21
 RTC_FORMAT_UINT = 0x5001
 RTC_FORMAT_UINT3 = 0x5003
 RTC_FORMAT_FLOAT = 0x9001
@@ -280,7 +284,9 @@ class Scene:
         self.device.check("add_triangles")
         return gid
 
-    def add_subdiv(self, verts, face_sizes, face_index, level=1.0, geom_id=None, displacement=None, user_data=None):
+    def add_subdiv(self, verts, face_sizes, face_index, level=1.0, geom_id=None, displacement=None, user_data=None,
+                   edge_creases=None, vertex_creases=None):
+        """edge_creases: (uint32 [k,2] vertex pairs, float32 [k] weights); vertex_creases: (uint32 [m], float32 [m])."""
         L = self.lib
         v = np.ascontiguousarray(verts, dtype=np.float32)
         vpad = np.zeros((v.shape[0] + 2, 3), dtype=np.float32)
@@ -293,6 +299,18 @@ class Scene:
         L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_FACE, 0, RTC_FORMAT_UINT, fs.ctypes.data, 0, 4, fs.shape[0])
         L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 0, RTC_FORMAT_UINT, fi.ctypes.data, 0, 4, fi.shape[0])
         L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_LEVEL, 0, RTC_FORMAT_FLOAT, lv.ctypes.data, 0, 4, lv.shape[0])
+        if edge_creases is not None:
+            ei = np.ascontiguousarray(edge_creases[0], dtype=np.uint32).reshape(-1, 2)
+            ew = np.ascontiguousarray(edge_creases[1], dtype=np.float32)
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_EDGE_CREASE_INDEX, 0, RTC_FORMAT_UINT + 1, ei.ctypes.data, 0, 8, ei.shape[0])
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_EDGE_CREASE_WEIGHT, 0, RTC_FORMAT_FLOAT, ew.ctypes.data, 0, 4, ew.shape[0])
+            self._keep += [ei, ew]
+        if vertex_creases is not None:
+            vi = np.ascontiguousarray(vertex_creases[0], dtype=np.uint32)
+            vw = np.ascontiguousarray(vertex_creases[1], dtype=np.float32)
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX_CREASE_INDEX, 0, RTC_FORMAT_UINT, vi.ctypes.data, 0, 4, vi.shape[0])
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX_CREASE_WEIGHT, 0, RTC_FORMAT_FLOAT, vw.ctypes.data, 0, 4, vw.shape[0])
+            self._keep += [vi, vw]
         if displacement is not None:
             L.rtcSetGeometryDisplacementFunction(g, C.cast(displacement, C.c_void_p))
             self._keep.append(displacement)
