@@ -12,6 +12,6 @@ for set in "TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_s
            "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "TCC_BUSY_avr GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   echo "pass $i: $set"
-  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcmem_$W/p$i -- python3 $R/bench.py --workload $W --steps 4 --warmup 1 --cpu-seconds 0 --no-others "$@" > $R/gpurun_out/pmcmem_$W/log$i.txt 2>&1 || { echo "pass $i failed"; grep -m2 -iE "error|exceed" $R/gpurun_out/pmcmem_$W/log$i.txt; exit 1; }
+  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/gpurun_out/pmcmem_$W/p$i -- python3 $R/bench.py --workload $W --inflight 1 --steps 4 --warmup 1 --cpu-seconds 0 --no-others "$@" > $R/gpurun_out/pmcmem_$W/log$i.txt 2>&1 || { echo "pass $i failed"; grep -m2 -iE "error|exceed" $R/gpurun_out/pmcmem_$W/log$i.txt; exit 1; }
   python3 $R/tools/pmc_summary.py $R/gpurun_out/pmcmem_$W/p$i
 done
