@@ -222,3 +222,24 @@ def test_non_quad_faces_parity(rtc, po, accel):
     orc.free()
     sc.release()
     dev.release()
+
+
+@pytest.mark.parametrize("accel", list(ACCELS))
+def test_gpu_reproduces_the_subdiv_golden_fixture(rtc, po, bomberman, accel):
+    """The committed vectors of tests/golden/bomberman_subdiv_hits.npz (oracle on the host-built records) against the
+    kernels, without the oracle in the loop: IDs exact, t/u/v within 1e-4 relative."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bomberman_subdiv_hits.npz"))
+    verts, fs, fi = bomberman
+    dev, sc = _build(rtc, accel, verts, fs, fi, int(g["level"]), int(g["compression"]))
+    rays = po.make_random_rays(int(g["count"]), verts.min(0), verts.max(0), seed=int(g["seed"]))  # generator only
+    sc.intersect1M(rays)
+    key = accel.split(".")[-1]
+    assert np.array_equal(rays["geomID"], g[f"{key}_geomID"]) and np.array_equal(rays["primID"], g[f"{key}_primID"])
+    hit = rays["geomID"] != INVALID
+    assert hit.sum() > 3000
+    for f in ("tfar", "u", "v"):
+        a, b = rays[f][hit].astype(np.float64), g[f"{key}_{f}"][hit].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(np.abs(b), 1e-3)), f
+    sc.release()
+    dev.release()

@@ -272,3 +272,31 @@ def test_leaf_quantiser_matches_the_forks_header(rtc, po):
             rcpF = delta * rng_  # same operation order as the device / oracle decode: (delta*range) * nibble + offset
             want = [off + rcpF * np.float32(z12 >> 4), off + rcpF * np.float32(z12 & 15), off + rcpF * np.float32(z34 >> 4), off + rcpF * np.float32(z34 & 15)]
             assert np.array_equal(out, np.array(want, np.float32))
+
+
+@pytest.mark.parametrize("accel,mode", [("default", 2), ("bvh4.compressed.box", 3), ("bvh4.compressed.leaf", 4), ("bvh4.compressed.grid", 5)])
+def test_subdiv_golden_fixture_is_reproduced(rtc, po, bomberman, accel, mode):
+    """tests/golden/bomberman_subdiv_hits.npz (tests/golden/make_golden_subdiv.py): host pipeline (tessellator, encoders,
+    outer BVH) + oracle reproduce the committed hits; guards all of them against silent changes."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bomberman_subdiv_hits.npz"))
+    verts, fs, fi = bomberman
+    dev = rtc.Device(f"gpu=none,subdiv_accel={accel}")
+    sc = rtc.Scene(dev)
+    sc.add_subdiv(verts, fs, fi)
+    sc.set_levels(int(g["level"]), int(g["compression"]))
+    sc.commit()
+    ordered = mode in (3, 4)
+    orc = po.SubdivScene(sc.accel_data(2), sc.stats()["primBytes"], mode, int(g["compression"]),
+                         qnodes=sc.accel_data(0) if ordered else None, root=sc.accel_root() if ordered else None)
+    rays = po.make_random_rays(int(g["count"]), verts.min(0), verts.max(0), seed=int(g["seed"]))
+    orc.intersect1M(rays, nthreads=4)
+    key = accel.split(".")[-1]
+    assert np.array_equal(rays["geomID"], g[f"{key}_geomID"]) and np.array_equal(rays["primID"], g[f"{key}_primID"])
+    hit = rays["geomID"] != 0xFFFFFFFF
+    for f in ("tfar", "u", "v"):
+        a, b = rays[f][hit].astype(np.float64), g[f"{key}_{f}"][hit].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(b), 1e-3)), f  # rcpps differs between CPU vendors
+    orc.free()
+    sc.release()
+    dev.release()
