@@ -1,6 +1,7 @@
 #include "bvh8_builder.h"
 
 #include <algorithm>
+#include <thread>
 
 namespace rtamd {
 
@@ -21,7 +22,20 @@ struct Binner
   const BuildSettings& cfg;
   std::vector<BinNode> tree;
 
-  Binner(std::vector<BuildPrim>& p, const BuildSettings& c) : prims(p), cfg(c) { tree.reserve(p.size() / 2 + 16); }
+  int forks = 0; // levels of the recursion that may still fork a thread
+
+  Binner(std::vector<BuildPrim>& p, const BuildSettings& c, size_t expect) : prims(p), cfg(c) { tree.reserve(expect / 2 + 16); }
+
+  // append another builder's subtree (indices are relative to its own vector); returns the new index of its root
+  int splice(const Binner& sub, int subRoot)
+  {
+    const int off = (int)tree.size();
+    for (const BinNode& n : sub.tree) {
+      tree.push_back(n);
+      if (n.left >= 0) { tree.back().left += off; tree.back().right += off; }
+    }
+    return subRoot + off;
+  }
 
   float blocks(size_t n) const { return float((n + cfg.blockSize - 1) / cfg.blockSize); }
 
@@ -103,8 +117,22 @@ struct Binner
       mid = (size_t)(it - prims.begin());
       if (mid == begin || mid == end) mid = begin + n / 2; // numerical corner case
     }
-    int l = build(begin, mid);
-    int r = build(mid, end);
+    int l, r;
+    if (forks > 0 && n > 65536) {
+      // the two halves are disjoint ranges of `prims`: build them concurrently in builders of their own, then splice
+      // (same splits as the sequential build, hence the same tree)
+      Binner L(prims, cfg, mid - begin), R(prims, cfg, end - mid);
+      L.forks = R.forks = forks - 1;
+      int lroot = -1, rroot = -1;
+      std::thread t([&]() { lroot = L.build(begin, mid); });
+      rroot = R.build(mid, end);
+      t.join();
+      l = splice(L, lroot);
+      r = splice(R, rroot);
+    } else {
+      l = build(begin, mid);
+      r = build(mid, end);
+    }
     tree[me].left = l;
     tree[me].right = r;
     return me;
@@ -236,7 +264,8 @@ BuildResult build_bvh8(std::vector<BuildPrim>& prims, const BuildSettings& setti
 {
   BuildResult out;
   if (prims.empty()) return out;
-  Binner binner(prims, settings);
+  Binner binner(prims, settings, prims.size());
+  for (unsigned t = settings.threads; t > 1; t >>= 1) binner.forks++;
   int root = binner.build(0, prims.size());
   Collapser c{binner.tree, prims, makeLeaf, out};
   out.nodes.reserve(prims.size() / 8 + 8);

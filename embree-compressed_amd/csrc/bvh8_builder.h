@@ -26,6 +26,7 @@ struct BuildSettings
   uint32_t maxLeaf = 28;     // always split above this size
   float travCost = 1.0f;
   float intCost = 1.0f;
+  unsigned threads = 1;      // host threads for the upper levels of the binary tree (subtrees above 64 k primitives)
 };
 
 struct BuildResult

@@ -278,6 +278,7 @@ static void build_triangle_accel(Scene* s)
     return make_tri_leaf(first, (uint32_t)(end - begin));
   };
   BuildSettings cfg; // block 4, min leaf 4, max leaf 28 (bvh_builder_sah.cpp:651-658)
+  cfg.threads = host_threads(s->device);
   BuildResult r = build_bvh8(bp, cfg, makeLeaf);
   A.nodes = std::move(r.nodes);
   A.root = r.root;

@@ -95,6 +95,7 @@ void build_eager(Scene* s, const std::vector<PatchGrid>& grids, Accel& A)
   auto makeLeaf = [&](const BuildPrim* prims, size_t begin, size_t end) -> uint32_t { return REF_LEAF | prims[begin].id; };
   BuildSettings cfg; // one primitive per leaf, bvh_builder_subdiv.cpp:845-851
   cfg.blockSize = 1; cfg.minLeaf = 1; cfg.maxLeaf = 1;
+  cfg.threads = host_threads(s->device);
   BuildResult r = build_bvh8(bp, cfg, makeLeaf);
   A.nodes = std::move(r.nodes);
   A.root = r.root;
@@ -143,6 +144,7 @@ void build_cbvh(Scene* s, const std::vector<PatchGrid>& grids, Accel& A, CbvhMod
   auto makeLeaf = [&](const BuildPrim* prims, size_t begin, size_t end) -> uint32_t { return REF_LEAF | prims[begin].id; };
   BuildSettings cfg;
   cfg.blockSize = 1; cfg.minLeaf = 1; cfg.maxLeaf = 1;
+  cfg.threads = host_threads(s->device);
   BuildResult r = build_bvh8(bp, cfg, makeLeaf);
   A.nodes = std::move(r.nodes);
   A.root = r.root;

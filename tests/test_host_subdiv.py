@@ -300,3 +300,21 @@ def test_subdiv_golden_fixture_is_reproduced(rtc, po, bomberman, accel, mode):
     orc.free()
     sc.release()
     dev.release()
+
+
+@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf"])
+def test_parallel_commit_is_deterministic(rtc, bomberman, accel):
+    """`threads=N` only changes who does the work: nodes and leaf records are byte-identical to the single-threaded build
+    (the upper levels of the BVH are built in forked subtrees and spliced, the cBVH blobs are encoded in parallel)."""
+    verts, fs, fi = bomberman
+    out = []
+    for cfg in ("threads=1", "threads=8"):
+        dev = rtc.Device(f"gpu=none,subdiv_accel={accel},{cfg}")
+        sc = rtc.Scene(dev)
+        sc.add_subdiv(verts, fs, fi)
+        sc.set_levels(5, 3)
+        sc.commit()
+        out.append((sc.accel_data(0).tobytes(), sc.accel_data(2).tobytes(), sc.accel_root()))
+        sc.release()
+        dev.release()
+    assert out[0] == out[1]
