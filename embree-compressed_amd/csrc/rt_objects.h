@@ -161,6 +161,8 @@ struct Geometry : RefCounted
   // buffer slots, keyed by (type, slot)
   std::map<std::pair<int, unsigned>, BufferView> views;
 
+  // face-varying data: topology (= index buffer slot) used by each vertex attribute slot (default 0)
+  std::vector<unsigned> attribTopology;
   // rtcInterpolate on subdivision meshes: refined buffers, built on first use, dropped by rtcCommitGeometry
   std::shared_ptr<void> interpCache;
   std::mutex interpMutex;

@@ -331,7 +331,17 @@ API void rtcSetGeometrySubdivisionMode(RTCGeometry h, unsigned int topologyID, e
   CATCH_END(devOf(h))
 }
 
-API void rtcSetGeometryVertexAttributeTopology(RTCGeometry h, unsigned int, unsigned int) { CATCH_BEGIN VERIFY(h); CATCH_END(devOf(h)) }
+API void rtcSetGeometryVertexAttributeTopology(RTCGeometry h, unsigned int vertexAttributeID, unsigned int topologyID)
+{
+  CATCH_BEGIN
+  VERIFY(h);
+  if (topologyID >= G(h)->topologyCount) RT_THROW(RTC_ERROR_INVALID_OPERATION, "invalid topology ID");
+  if (vertexAttributeID >= 65536) RT_THROW(RTC_ERROR_INVALID_OPERATION, "invalid vertex attribute ID");
+  if (G(h)->attribTopology.size() <= vertexAttributeID) G(h)->attribTopology.resize(vertexAttributeID + 1, 0u);
+  G(h)->attribTopology[vertexAttributeID] = topologyID;
+  G(h)->committed = false;
+  CATCH_END(devOf(h))
+}
 
 API void rtcSetGeometryDisplacementFunction(RTCGeometry h, RTCDisplacementFunctionN f)
 {

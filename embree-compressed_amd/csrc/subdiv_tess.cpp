@@ -558,14 +558,19 @@ static void refine_polygons(const std::vector<D3>& P, const std::vector<std::vec
 // generic Catmull-Clark step, where every N-gon (quads included) is N sub-quads (`firstStep` = false, `faceMap` has
 // one entry per sub-quad).  A face is valid if it is not a hole, its indices are in range and its vertices are finite
 // (SubdivMesh::valid).
+// `values` / `topo`: refine per-vertex data other than the positions, connected by index buffer slot `topo` (face-varying
+// vertex attributes, rtcSetGeometryVertexAttributeTopology); the faces and their validity always come from topology 0.
 static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std::vector<FaceMap>& faceMap, bool& firstStep,
-                                           const std::vector<D3>* values = nullptr) // values: refine these instead of the positions
+                                           const std::vector<D3>* values = nullptr, unsigned topo = 0)
 {
   const BufferView* vb = geom->view(RTC_BUFFER_TYPE_VERTEX, 0);
   const BufferView* ib = geom->view(RTC_BUFFER_TYPE_INDEX, 0);
   const BufferView* fb = geom->view(RTC_BUFFER_TYPE_FACE, 0);
   if (!vb || !vb->valid() || !ib || !ib->valid() || !fb || !fb->valid())
     RT_THROW(RTC_ERROR_INVALID_OPERATION, "subdivision geometry needs vertex, index and face buffers");
+  const BufferView* ibt = topo ? geom->view(RTC_BUFFER_TYPE_INDEX, topo) : ib;
+  if (topo && (!ibt || !ibt->valid() || ibt->count != ib->count || !values))
+    RT_THROW(RTC_ERROR_INVALID_OPERATION, "topology without a matching index buffer");
   // crease buffers (SubdivMesh::edgeCreaseMap / vertexCreaseMap, scene_subdiv_mesh.cpp:150-190): pairs of vertex indices
   // with a weight each, vertex indices with a weight each
   std::unordered_map<uint64_t, float> crease;
@@ -592,7 +597,8 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
       }
     }
   }
-  const RTCSubdivisionMode mode = geom->subdivMode.empty() ? RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY : geom->subdivMode[0];
+  const RTCSubdivisionMode mode = topo < geom->subdivMode.size() ? geom->subdivMode[topo] : RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY;
+  if (topo) { crease.clear(); vcrease.clear(); } // crease buffers address the vertices of the first topology
 
   std::vector<D3> P(vb->count);
   for (size_t i = 0; i < vb->count; i++) {
@@ -622,6 +628,11 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
       if (q[k] >= P.size()) ok = false;
       else if (!(std::isfinite(P[q[k]].x) && std::isfinite(P[q[k]].y) && std::isfinite(P[q[k]].z))) ok = false;
     }
+    if (ok && topo) // same face, other connectivity
+      for (unsigned k = 0; k < nv; k++) {
+        q[k] = *(const unsigned*)ibt->at(cursor + k);
+        if (q[k] >= values->size()) ok = false;
+      }
     cursor += nv;
     if (!ok) continue;
     if (nv != 4) allQuads = false;
@@ -630,7 +641,8 @@ static RTCSubdivisionMode build_base_level(const Geometry* geom, Level& cur, std
   }
   faceMap.clear();
   firstStep = allQuads;
-  if (values) { // same topology and face validity, other per-vertex data (vertex attributes)
+  if (values) { // same faces and face validity, other per-vertex data (vertex attributes)
+    if (topo) P.resize(values->size());
     for (size_t i = 0; i < P.size(); i++) P[i] = i < values->size() ? (*values)[i] : D3();
   }
   if (allQuads) {
@@ -854,16 +866,26 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
   if (!src || !src->valid()) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "rtcInterpolate: buffer slot is not bound");
   if (args->valueCount > 256) RT_THROW(RTC_ERROR_INVALID_OPERATION, "maximally 256 floating point values can be interpolated per vertex");
 
+  unsigned topo = 0;
+  if (args->bufferType == RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE && args->bufferSlot < geom->attribTopology.size()) topo = geom->attribTopology[args->bufferSlot];
+  typedef std::map<unsigned, std::shared_ptr<SubdivInterpCache>> CacheMap; // one per topology
   std::shared_ptr<SubdivInterpCache> cache;
   {
     std::lock_guard<std::mutex> g(geom->interpMutex);
-    cache = std::static_pointer_cast<SubdivInterpCache>(geom->interpCache);
-    if (!cache) { // topology part, once per commit of the geometry
+    if (!geom->interpCache) geom->interpCache = std::make_shared<CacheMap>();
+    CacheMap& caches = *std::static_pointer_cast<CacheMap>(geom->interpCache);
+    cache = caches[topo];
+    if (!cache) { // connectivity part, once per commit of the geometry and topology
       cache = std::make_shared<SubdivInterpCache>();
       Level cur;
       std::vector<FaceMap> faceMap;
       bool first = true;
-      const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first);
+      std::vector<D3> dummy;
+      if (topo) { // only the connectivity matters here: any per-vertex values of the right count
+        const BufferView* any = geom->view(args->bufferType, args->bufferSlot);
+        dummy.assign(any->count, D3());
+      }
+      const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first, topo ? &dummy : nullptr, topo);
       cache->mixed = !first;
       const BufferView* fb = geom->view(RTC_BUFFER_TYPE_FACE, 0);
       cache->primToFace.assign(fb->count, -1);
@@ -891,7 +913,7 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
             const uint32_t q = (uint32_t)(f * n * n + (size_t)j * n + i);
             for (uint32_t v : {cur.grid[f][j * w + i], cur.grid[f][j * w + i + 1], cur.grid[f][(j + 1) * w + i + 1], cur.grid[f][(j + 1) * w + i]}) cache->vqList[fill[v]++] = q;
           }
-      geom->interpCache = cache;
+      caches[topo] = cache;
     }
   }
   const unsigned groups = (args->valueCount + 2) / 3;
@@ -914,7 +936,7 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
         InterpChannels ch;
         std::vector<FaceMap> faceMap;
         bool first = true;
-        const RTCSubdivisionMode mode = build_base_level(geom, ch.lvl, faceMap, first, &values);
+        const RTCSubdivisionMode mode = build_base_level(geom, ch.lvl, faceMap, first, &values, topo);
         refine_to_interp_level(ch.lvl, mode, first, &ch.limit, nullptr);
         c.push_back(std::move(ch));
       }

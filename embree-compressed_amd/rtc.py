@@ -148,6 +148,9 @@ def load_library(path=LIB_PATH):
         "rtcDetachGeometry": (None, [vp, u]),
         "rtcGetGeometry": (vp, [vp, u]),
         "rtcSetGeometryVertexAttributeCount": (None, [vp, u]),
+        "rtcSetGeometryTopologyCount": (None, [vp, u]),
+        "rtcSetGeometrySubdivisionMode": (None, [vp, u, C.c_int]),
+        "rtcSetGeometryVertexAttributeTopology": (None, [vp, u, u]),
         "rtcInterpolate": (None, [C.POINTER(RTCInterpolateArguments)]),
         "rtcInterpolateN": (None, [C.POINTER(RTCInterpolateNArguments)]),
         "rtcSetSceneLevels": (None, [vp, u, u]),
@@ -336,9 +339,19 @@ class Scene:
         self._keep += [intersect, occluded]
         self.device.check("set_filters")
 
-    def set_vertex_attribute(self, geom_id, slot, values):
-        """Bind a float32 [nv, k] (k <= 4) array as vertex attribute `slot` of an attached geometry and re-commit it."""
+    def set_vertex_attribute(self, geom_id, slot, values, topology_index=None, mode=None):
+        """Bind a float32 [nv, k] (k <= 4) array as vertex attribute `slot` of an attached geometry and re-commit it.
+        topology_index: uint32 face-vertex indices of a second topology for this attribute (face-varying data); mode: its
+        RTCSubdivisionMode."""
         L = self.lib
+        if topology_index is not None:
+            g = L.rtcGetGeometry(self.handle, geom_id)
+            ti = np.ascontiguousarray(topology_index, dtype=np.uint32)
+            L.rtcSetGeometryTopologyCount(g, 2)
+            L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_INDEX, 1, RTC_FORMAT_UINT, ti.ctypes.data, 0, 4, ti.shape[0])
+            if mode is not None:
+                L.rtcSetGeometrySubdivisionMode(g, 1, mode)
+            self._keep.append(ti)
         a = np.ascontiguousarray(values, dtype=np.float32)
         pad = np.zeros((a.shape[0] + 2, a.shape[1]), dtype=np.float32)
         pad[: a.shape[0]] = a
@@ -346,6 +359,8 @@ class Scene:
         L.rtcSetGeometryVertexAttributeCount(g, slot + 1)
         fmt = {1: RTC_FORMAT_FLOAT, 2: RTC_FORMAT_FLOAT + 1, 3: RTC_FORMAT_FLOAT3, 4: RTC_FORMAT_FLOAT3 + 1}[a.shape[1]]
         L.rtcSetSharedGeometryBuffer(g, RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot, fmt, pad.ctypes.data, 0, 4 * a.shape[1], a.shape[0])
+        if topology_index is not None:
+            L.rtcSetGeometryVertexAttributeTopology(g, slot, 1)
         L.rtcCommitGeometry(g)
         self._keep.append(pad)
         self.device.check("set_vertex_attribute")

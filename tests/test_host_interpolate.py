@@ -122,3 +122,46 @@ def test_subdiv_interpolation_agrees_with_the_tessellator_and_itself(rtc, bomber
         sc.interpolate(gid, 10 ** 6, 0.5, 0.5)
     sc.release()
     dev.release()
+
+
+def test_face_varying_attribute_topology(rtc):
+    """A vertex attribute with its own topology (rtcSetGeometryTopologyCount / rtcSetGeometryVertexAttributeTopology): every
+    face owns four attribute vertices of its own (a texture atlas with a seam on every edge).  With PIN_ALL the attribute is
+    the bilinear interpolation of the face's four values; with the position topology re-used it equals the plain attribute."""
+    verts, faces, nu, nv = _torus()
+    nf = len(faces)
+    dev = rtc.Device("gpu=none")
+    sc = rtc.Scene(dev)
+    gid = sc.add_subdiv(verts, np.full(nf, 4, np.uint32), faces.ravel())
+    rng = np.random.RandomState(12)
+    per_face = rng.rand(nf * 4, 2).astype(np.float32)               # 4 private attribute vertices per face
+    sc.set_vertex_attribute(gid, 0, per_face, topology_index=np.arange(nf * 4, dtype=np.uint32), mode=4)  # RTC_SUBDIVISION_MODE_PIN_ALL
+    sc.commit()
+    for _ in range(40):
+        f = int(rng.randint(nf))
+        u, v = rng.rand(2)
+        c = per_face[4 * f: 4 * f + 4].astype(np.float64)            # corners in face order: (0,0) (1,0) (1,1) (0,1)
+        want = (1 - u) * (1 - v) * c[0] + u * (1 - v) * c[1] + u * v * c[2] + (1 - u) * v * c[3]
+        P, du, dv = sc.interpolate(gid, f, float(u), float(v), buffer_type=rtc.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot=0, count=2, derivs=1)[:3]
+        assert np.abs(P - want).max() < 1e-6
+        assert np.abs(du - ((1 - v) * (c[1] - c[0]) + v * (c[2] - c[3]))).max() < 1e-5
+        assert np.abs(dv - ((1 - u) * (c[3] - c[0]) + u * (c[2] - c[1]))).max() < 1e-5
+    # positions still use topology 0
+    assert np.abs(sc.interpolate(gid, 3, 0.5, 0.5, derivs=0)[0]).max() > 0
+    # second topology identical to the first: same as an ordinary attribute
+    sc2 = rtc.Scene(dev)
+    g2 = sc2.add_subdiv(verts, np.full(nf, 4, np.uint32), faces.ravel())
+    col = rng.rand(len(verts), 3).astype(np.float32)
+    sc2.set_vertex_attribute(g2, 0, col)
+    sc2.set_vertex_attribute(g2, 1, col, topology_index=faces.ravel())
+    sc2.commit()
+    for _ in range(20):
+        f = int(rng.randint(nf))
+        u, v = (float(x) for x in rng.rand(2))
+        a = sc2.interpolate(g2, f, u, v, buffer_type=rtc.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot=0)
+        b = sc2.interpolate(g2, f, u, v, buffer_type=rtc.RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE, slot=1)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    sc.release()
+    sc2.release()
+    dev.release()
