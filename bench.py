@@ -60,7 +60,10 @@ def parse():
     ap.add_argument("--no-others", action="store_true", help="skip the short tri / eager side runs")
     ap.add_argument("--inflight", type=int, default=4,
                     help="ray batches in flight: step s is enqueued on HIP stream s %% inflight (1 = one stream, strictly back-to-back)")
-    ap.add_argument("--rays-kind", default="random", choices=["random", "primary"],
+    ap.add_argument("--query", default="intersect", choices=["intersect", "occluded"],
+                    help="closest hit (rtcIntersect1M on RTCRayHit[80B]) or any hit (rtcOccluded1M on RTCRay[48B]); occluded is meant "
+                         "for --rays-kind secondary (shadow rays)")
+    ap.add_argument("--rays-kind", default="random", choices=["random", "primary", "secondary"],
                     help="random: the metric's incoherent bbox rays; primary: BASELINE config 4, 1920x1080 camera rays of bomberman.ecs")
     return ap.parse_args()
 
@@ -126,7 +129,7 @@ def cpu_baseline(sc, rtc, workload, mesh, levels, lo, hi, m, budget_s):
             "sample": f"{reps} x {m} rays of the same generator (seed 12345), {what} (oracle/liboracle.so), {cores} pthreads, blocks of 1024"}
 
 
-def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world):
+def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world, occluded=False):
     """W untimed + K timed steps; step s goes to streams[s % len(streams)] (the library keeps per-launch scratch, so
     batches on different streams overlap: the drain of one batch runs under the start of the next).  Returns the
     host-clock time of the timed region and, for ONE stream, the HIP-event time per launch on that stream."""
@@ -135,10 +138,12 @@ def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world):
         if world > 1:
             dist.barrier()
 
+    trace = sc.occluded1M if occluded else sc.intersect1M
+
     def step(s):
         st = streams[s % len(streams)]
         dev.set_stream(st.cuda_stream)
-        sc.intersect1M(bufs[s], check=False)
+        trace(bufs[s], check=False)
 
     # every stream (and every per-launch context of the library) is exercised before the clock starts: first use of a
     # HIP stream costs milliseconds.  The extra untimed steps re-trace warm-up batches, never timed ones.
@@ -147,7 +152,7 @@ def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world):
     for s in range(W, 2 * len(streams) if len(streams) > 1 else 0):
         st = streams[s % len(streams)]
         dev.set_stream(st.cuda_stream)
-        sc.intersect1M(bufs[s % max(W, 1)], check=False)
+        trace(bufs[s % max(W, 1)], check=False)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -204,25 +209,42 @@ def main():
         primary = raygen.make_primary_rays()
         m = primary.shape[0]
 
+    occluded = args.query == "occluded"
+
     def measure(workload, K, W):
+        nonlocal m
         dev, sc = build_scene(rtc, local_rank, workload, mesh, levels)
         dev.set_stream(stream.cuda_stream)
         # distinct batches per step and per rank, generated on the host, resident in HBM before timing starts
         nb = 2 * (K + W) + 1 if nfl > 1 else K + W + 1
-        if primary is not None:  # the same camera frame every step, but a fresh copy (a trace modifies rays in place)
-            bufs = [torch.from_numpy(primary).to("cuda") for s in range(nb)]
+        if args.rays_kind == "secondary":
+            # config 5, wavefront style: trace the camera frame once on THIS scene, record one bounce ray and one shadow ray
+            # per hit (raygen.make_secondary_rays); every step traces a fresh copy of the recorded batch
+            first = torch.from_numpy(raygen.make_primary_rays()).to("cuda")
+            sc.intersect1M(first)
+            dev.synchronize()
+            bounce, shadow = raygen.make_secondary_rays(first.cpu().numpy(), seed=11 + rank)
+            tmpl = shadow if occluded else bounce
+            m = tmpl.shape[0]
+            bufs = [torch.from_numpy(tmpl).to("cuda") for s in range(nb)]
+        elif primary is not None:  # the same camera frame every step, but a fresh copy (a trace modifies rays in place)
+            bufs = [torch.from_numpy(primary[:, :48].copy() if occluded else primary).to("cuda") for s in range(nb)]
         else:
-            bufs = [torch.from_numpy(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))).to("cuda") for s in range(nb)]
+            bufs = [torch.from_numpy(np.ascontiguousarray(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))[:, :48 if occluded else 80])).to("cuda")
+                    for s in range(nb)]
         torch.cuda.synchronize()
-        cnt = sc.intersect1M_counted(bufs[nb - 1])  # extra batch: work counters -> algorithmic bytes per ray
+        cnt = (sc.occluded1M_counted if occluded else sc.intersect1M_counted)(bufs[nb - 1])  # extra batch: work counters -> algorithmic bytes per ray
         # pass 1, one stream: the kernel alone, HIP-event time per launch (the roofline figure; agrees with rocprofv3
         # --kernel-trace of `bench.py --inflight 1`)
-        elapsed1, kernel_ms = run_loop(torch, dist, sc, dev, streams[:1], bufs, K, W, world)
-        hits = int((bufs[W].view(torch.int32)[:, 18] != -1).sum().item())
+        elapsed1, kernel_ms = run_loop(torch, dist, sc, dev, streams[:1], bufs, K, W, world, occluded)
+        if occluded:
+            hits = int(torch.isneginf(bufs[W].view(torch.float32)[:, 8]).sum().item())
+        else:
+            hits = int((bufs[W].view(torch.int32)[:, 18] != -1).sum().item())
         # pass 2 (the reported value), fresh batches: `inflight` batches in flight on as many streams
         elapsed = elapsed1
         if nfl > 1:
-            elapsed, _ = run_loop(torch, dist, sc, dev, streams, bufs[K + W:], K, W, world)
+            elapsed, _ = run_loop(torch, dist, sc, dev, streams, bufs[K + W:], K, W, world, occluded)
         return dev, sc, cnt, elapsed, kernel_ms, hits, elapsed1
 
     dev, sc, cnt, elapsed, kernel_ms, hits, elapsed1 = measure(args.workload, K, W)
@@ -232,13 +254,14 @@ def main():
     n_prim = cnt["primTests"] / max(cnt["rays"], 1)
     n_inner = cnt["innerVisits"] / max(cnt["rays"], 1)
     # implementation's own visits x record sizes; a subdiv leaf visit is priced at its whole record
-    bytes_per_ray = IO_BYTES_PER_RAY + n_node * st["nodeBytes"] + n_prim * st["primBytes"]
+    io_bytes = 48 + 4 if occluded else IO_BYTES_PER_RAY  # any hit: RTCRay read, tfar written
+    bytes_per_ray = io_bytes + n_node * st["nodeBytes"] + n_prim * st["primBytes"]
 
     if rank == 0:
         _, _, _, tag, desc = WORKLOADS[args.workload]
         achieved = bytes_per_ray * m / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None)
-        if m == 1_000_000 and levels == (6, 3) and primary is None:  # the committed PMC passes were taken on this exact workload
+        if m == 1_000_000 and levels == (6, 3) and args.rays_kind == "random" and not occluded:  # the committed PMC passes were taken on this exact workload
             traffic, traffic_src = pmc_traffic(tag, args.workload)
         out = {
             "metric": "Mrays/s (incoherent) on bomberman displaced-subdiv scene, device-resident ray batches",
@@ -254,9 +277,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}; {m} "
-                                   + ("random incoherent rays per step (drand48 LCG, bbox-uniform endpoints), " if primary is None else
-                                      "coherent primary rays per step (config 4: 1920x1080, bomberman.ecs camera, 8x8 tile order), ")
-                                   + "rtcIntersect1M on device-resident RTCRayHit[80B]",
+                                   + {"random": "random incoherent rays per step (drand48 LCG, bbox-uniform endpoints), ",
+                                      "primary": "coherent primary rays per step (config 4: 1920x1080, bomberman.ecs camera, 8x8 tile order), ",
+                                      "secondary": "incoherent rays recorded from the config-4 camera frame (config 5: one bounce ray / one shadow ray "
+                                                   "per primary hit, tnear 0.001), "}[args.rays_kind]
+                                   + ("rtcOccluded1M on device-resident RTCRay[48B]" if occluded else "rtcIntersect1M on device-resident RTCRayHit[80B]"),
                        "rays_per_step_per_gpu": m, "accel_kind": st["accelKind"], "bvh_nodes": st["nodeCount"], "leaf_records": st["primCount"],
                        "leaf_record_bytes": st["primBytes"], "accel_bytes": st["totalBytes"], "hits_first_timed_batch": hits,
                        "batches_in_flight": nfl,

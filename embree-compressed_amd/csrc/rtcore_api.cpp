@@ -763,6 +763,16 @@ API void rtcamdIntersect1MCounted(RTCScene h, struct RTCIntersectContext* ctx, s
   CATCH_END(devOf(h))
 }
 
+API void rtcamdOccluded1MCounted(RTCScene h, struct RTCIntersectContext* ctx, struct RTCRay* ray, unsigned int M, size_t byteStride,
+                                 struct RTCAMDTraceCounters* counters)
+{
+  CATCH_BEGIN
+  VERIFY(h);
+  VERIFY(counters);
+  trace_batch(S(h), ray, M, byteStride, true, ctx, (TraceCounters*)counters);
+  CATCH_END(devOf(h))
+}
+
 API const void* rtcamdGetAccelData(RTCScene h, unsigned int kind, size_t* byteSize)
 {
   CATCH_BEGIN

@@ -92,6 +92,41 @@ def make_primary_rays(width=1920, height=1080, frm=(18.21240425, 20.05745888, 15
     return rec.view(np.uint8).reshape(m, RAYHIT_BYTES)
 
 
+def make_secondary_rays(traced, seed=11, light=(50.0, 400.0, -120.0), tnear=0.001):
+    """Incoherent rays of BASELINE config 5 (pathtracer), recorded wavefront-style from a traced batch (uint8 [M,80] records
+    or the matching structured array): for every hit, one bounce ray from the hit point in a cosine-like lobe around the
+    shading-side normal (tnear = 0.001, tfar = inf; pathtracer_device.cpp:1442-1535 traces such rays with rtcIntersect1)
+    and one shadow ray towards a point light (tfar = distance; rtcOccluded1).  Returns (bounce uint8 [n,80], shadow uint8
+    [n,48]); n = number of hits."""
+    f = np.ascontiguousarray(traced).view(np.uint8).reshape(-1, RAYHIT_BYTES).view(np.float32)
+    w = f.view(np.uint32)
+    hit = w[:, 18] != 0xFFFFFFFF
+    f, n = f[hit], int(hit.sum())
+    o = (f[:, 0:3] + f[:, 8:9] * f[:, 4:7]).astype(np.float32)
+    ng = f[:, 12:15].astype(np.float64)
+    ng /= np.maximum(np.linalg.norm(ng, axis=1, keepdims=True), 1e-30)
+    ng[(ng * f[:, 4:7]).sum(1) > 0] *= -1  # face the incoming ray
+    rng = np.random.RandomState(seed)
+    r = rng.normal(size=(n, 3))
+    r /= np.linalg.norm(r, axis=1, keepdims=True)
+    d = ng + 0.999 * r
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rec = np.zeros((n, 20), dtype=np.float32)
+    rec[:, 0:3], rec[:, 3], rec[:, 4:7], rec[:, 8] = o, tnear, d.astype(np.float32), np.inf
+    rw = rec.view(np.uint32)
+    rw[:, 9] = 0xFFFFFFFF
+    rw[:, 10] = np.arange(n, dtype=np.uint32)
+    rw[:, 17:20] = 0xFFFFFFFF
+    ld = np.asarray(light, np.float64)[None, :] - o
+    dist = np.linalg.norm(ld, axis=1)
+    sh = np.zeros((n, 12), dtype=np.float32)
+    sh[:, 0:3], sh[:, 3], sh[:, 4:7], sh[:, 8] = o, tnear, (ld / dist[:, None]).astype(np.float32), dist.astype(np.float32)
+    sw = sh.view(np.uint32)
+    sw[:, 9] = 0xFFFFFFFF
+    sw[:, 10] = np.arange(n, dtype=np.uint32)
+    return rec.view(np.uint8).reshape(n, RAYHIT_BYTES), sh.view(np.uint8).reshape(n, 48)
+
+
 def shard_range(total, rank, world):
     """Contiguous ray-index range of `rank`: [rank*total/world, (rank+1)*total/world)."""
     return (rank * total) // world, ((rank + 1) * total) // world

@@ -173,6 +173,7 @@ def load_library(path=LIB_PATH):
         "rtcamdGetDeviceOrdinal": (C.c_int, [vp]),
         "rtcamdGetSceneStats": (None, [vp, C.POINTER(RTCAMDSceneStats)]),
         "rtcamdIntersect1MCounted": (None, [vp, C.POINTER(RTCIntersectContext), vp, u, sz, C.POINTER(RTCAMDTraceCounters)]),
+        "rtcamdOccluded1MCounted": (None, [vp, C.POINTER(RTCIntersectContext), vp, u, sz, C.POINTER(RTCAMDTraceCounters)]),
         "rtcamdGetAccelData": (vp, [vp, u, C.POINTER(sz)]),
         "rtcamdGetAccelRoot": (u, [vp]),
         "rtcamdDebugCbvhLeafCodec": (None, [vp, vp, C.c_float, vp, C.POINTER(C.c_float)]),
@@ -448,6 +449,14 @@ class Scene:
         cnt = RTCAMDTraceCounters()
         self.lib.rtcamdIntersect1MCounted(self.handle, C.byref(ctx), ptr, m, stride, C.byref(cnt))
         self.device.check("rtcamdIntersect1MCounted")
+        return {n: (list(getattr(cnt, n)) if n.endswith("Hist") else getattr(cnt, n)) for n, _ in RTCAMDTraceCounters._fields_}
+
+    def occluded1M_counted(self, rays, ctx=None):
+        ptr, m, stride = _ptr_and_count(rays)
+        ctx = ctx or make_context()
+        cnt = RTCAMDTraceCounters()
+        self.lib.rtcamdOccluded1MCounted(self.handle, C.byref(ctx), ptr, m, stride, C.byref(cnt))
+        self.device.check("rtcamdOccluded1MCounted")
         return {n: (list(getattr(cnt, n)) if n.endswith("Hist") else getattr(cnt, n)) for n, _ in RTCAMDTraceCounters._fields_}
 
     def stats(self):

@@ -92,6 +92,10 @@ struct RTCAMDTraceCounters
 RTC_API void rtcamdIntersect1MCounted(RTCScene scene, struct RTCIntersectContext* context, struct RTCRayHit* rayhit,
                                       unsigned int M, size_t byteStride, struct RTCAMDTraceCounters* counters);
 
+/* The same for an any-hit batch (rtcOccluded1M semantics). */
+RTC_API void rtcamdOccluded1MCounted(RTCScene scene, struct RTCIntersectContext* context, struct RTCRay* ray, unsigned int M,
+                                     size_t byteStride, struct RTCAMDTraceCounters* counters);
+
 /* Read-only views of the host copy of the committed accel (valid until the next commit / release).
  * Test infrastructure: lets an external checker walk the exact structure the kernels traverse.
  * kind: 0 = BVH8 nodes, 1 = primitive records, 2 = subdiv leaf blobs, 3 = blob offset table. */

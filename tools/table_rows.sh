@@ -12,3 +12,10 @@ run --workload tri --rays-kind primary
 run --workload cbvh.leaf --levels 8,3
 run --workload cbvh.leaf --levels 8,3 --rays-kind primary
 run --workload eager --levels 8,3 --rays-kind primary
+# config 5: recorded bounce rays (closest hit) and shadow rays (any hit)
+run --workload cbvh.leaf --rays-kind secondary
+run --workload eager --rays-kind secondary
+run --workload tri --rays-kind secondary
+run --workload eager --rays-kind secondary --query occluded
+run --workload tri --rays-kind secondary --query occluded
+run --workload tri --query occluded
