@@ -95,6 +95,7 @@ struct Device : RefCounted
   // four batches in flight 256 / 32 / 2 is +15-20 % over 128 / 24 / 3 (each kernel leaves the third wave slot of a SIMD
   // to the other batches, and takes its rays in fewer, larger grabs).
   uint32_t tuneChunk = 256, tuneLeafBatch = 32, tuneBlocksPerCU = 2;
+  uint32_t tunePoolKernel = 0; // env RTAMD_KERNEL=pool selects the ray-pool skeleton (trace_pool.hip.h)
 
   explicit Device(const char* cfg);
   ~Device() override;

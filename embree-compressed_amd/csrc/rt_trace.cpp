@@ -37,10 +37,19 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   p.instID = instID;
   p.occluded = occluded ? 1u : 0u;
   p.gridBlocks = trace_grid_blocks(M, dev->numCUs);
+  p.poolKernel = dev->tunePoolKernel;
   // worst-case stack: 7 siblings per level plus the entry being expanded
   const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
-  p.spillDepth = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
-  Device::LaunchCtx& ctx = dev->acquireLaunchCtx((size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u);
+  size_t spillBytes;
+  if (p.poolKernel) { // one overflow column per ray slot of every resident wavefront
+    p.gridBlocks = (uint32_t)dev->numCUs * TRACE_POOL_BLOCKS_PER_CU;
+    p.spillDepth = worst > (uint32_t)TRACE_POOL_STACK ? worst - TRACE_POOL_STACK : 0u;
+    spillBytes = (size_t)p.gridBlocks * (TRACE_POOL_BLOCK / 64) * TRACE_POOL_SLOTS * (size_t)p.spillDepth * 8u + 16u;
+  } else {
+    p.spillDepth = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
+    spillBytes = (size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u;
+  }
+  Device::LaunchCtx& ctx = dev->acquireLaunchCtx(spillBytes);
   p.spill = ctx.spill;
   p.counters = dCounters;
   p.cbvhLevels = s->compressionLevel;

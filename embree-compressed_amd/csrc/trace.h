@@ -30,11 +30,14 @@ struct LaunchParams
   // nullptr for ordinary launches.
   const uint32_t* exclOffsets;
   const uint2* exclPairs;
+  uint32_t poolKernel;     // 1: ray-pool skeleton (trace_pool.hip.h), 0: lane-per-ray skeleton (trace_loop.hip.h)
 };
 
 static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)
 static const int TRACE_QUEUE_STRIDE = 32; // u32 words between two work-queue heads (128 B: one L2 line each)
 static const int TRACE_BLOCK = 256;     // 4 wavefronts per workgroup
+// ray-pool skeleton (trace_pool.hip.h): workgroup size, ray slots per wavefront, LDS stack entries per slot, workgroups per CU
+static const int TRACE_POOL_BLOCK = 128, TRACE_POOL_SLOTS = 128, TRACE_POOL_STACK = 8, TRACE_POOL_BLOCKS_PER_CU = 4;
 #ifndef TRACE_LDS_STACK_ENTRIES
 #define TRACE_LDS_STACK_ENTRIES 16
 #endif

@@ -70,6 +70,16 @@ template <> struct TravRay<true> // node_intersector1.h:108-129
   __device__ __forceinline__ bool negx() const { return !(rnx >= 0.0f); }
   __device__ __forceinline__ bool negy() const { return !(rny >= 0.0f); }
   __device__ __forceinline__ bool negz() const { return !(rnz >= 0.0f); }
+  // seven words, for kernels that park the per-ray constants outside the registers (trace_pool.hip.h)
+  static constexpr int WORDS = 7;
+  __device__ __forceinline__ void store(float* f, int stride) const
+  {
+    f[0] = ox; f[stride] = oy; f[2 * stride] = oz; f[3 * stride] = rnx; f[4 * stride] = rny; f[5 * stride] = rnz; f[6 * stride] = tnear;
+  }
+  __device__ __forceinline__ void load(const float* f, int stride)
+  {
+    ox = f[0]; oy = f[stride]; oz = f[2 * stride]; rnx = f[3 * stride]; rny = f[4 * stride]; rnz = f[5 * stride]; tnear = f[6 * stride];
+  }
   __device__ __forceinline__ void init(const RayState& r)
   {
     ox = r.ox; oy = r.oy; oz = r.oz;
@@ -100,6 +110,15 @@ template <> struct TravRay<false> // node_intersector1.h:33-57, AVX2 form with o
   __device__ __forceinline__ bool negx() const { return !(rx >= 0.0f); }
   __device__ __forceinline__ bool negy() const { return !(ry >= 0.0f); }
   __device__ __forceinline__ bool negz() const { return !(rz >= 0.0f); }
+  static constexpr int WORDS = 7;
+  __device__ __forceinline__ void store(float* f, int stride) const
+  {
+    f[0] = rx; f[stride] = ry; f[2 * stride] = rz; f[3 * stride] = orx; f[4 * stride] = ory; f[5 * stride] = orz; f[6 * stride] = tnear;
+  }
+  __device__ __forceinline__ void load(const float* f, int stride)
+  {
+    rx = f[0]; ry = f[stride]; rz = f[2 * stride]; orx = f[3 * stride]; ory = f[4 * stride]; orz = f[5 * stride]; tnear = f[6 * stride];
+  }
   __device__ __forceinline__ void init(const RayState& r)
   {
     const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx;

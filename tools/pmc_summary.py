@@ -7,7 +7,7 @@ for d in sys.argv[1:]:
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name']
-            if 'trace_kernel' in k and 'false, false, true>' in k:
+            if ('trace_kernel' in k or 'trace_pool_kernel' in k) and 'false, false, true>' in k:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
         for c, x in sorted(agg.items()):
             print('%-40s %16.1f  (n=%d)' % (c, sum(x) / len(x), len(x)))
