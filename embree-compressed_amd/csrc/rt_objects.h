@@ -95,7 +95,10 @@ struct Device : RefCounted
   // four batches in flight 256 / 32 / 2 is +15-20 % over 128 / 24 / 3 (each kernel leaves the third wave slot of a SIMD
   // to the other batches, and takes its rays in fewer, larger grabs).
   uint32_t tuneChunk = 256, tuneLeafBatch = 32, tuneBlocksPerCU = 2;
-  uint32_t tunePoolKernel = 0; // env RTAMD_KERNEL=pool selects the ray-pool skeleton (trace_pool.hip.h)
+  // traversal skeleton: 0 lane-per-ray (trace_loop.hip.h), 1 ray pool (trace_pool.hip.h), 2 by batch size: the pool kernel's
+  // steady state is 14 % faster, its drain slower - it wins from ~2.5 M rays per launch on (env RTAMD_KERNEL=lane|pool|auto)
+  uint32_t tunePoolKernel = 2;
+  uint32_t tunePoolMinRays = 2500000;
 
   explicit Device(const char* cfg);
   ~Device() override;

@@ -37,7 +37,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   p.instID = instID;
   p.occluded = occluded ? 1u : 0u;
   p.gridBlocks = trace_grid_blocks(M, dev->numCUs);
-  p.poolKernel = dev->tunePoolKernel;
+  p.poolKernel = dev->tunePoolKernel == 2u ? (M >= dev->tunePoolMinRays ? 1u : 0u) : dev->tunePoolKernel;
   // worst-case stack: 7 siblings per level plus the entry being expanded
   const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
   size_t spillBytes;

@@ -11,15 +11,16 @@
 //   leaf : 64 rays intersect their leaf; a hit is written to the ray record at once       -> pop
 //   pop  : inline after node / leaf: next stack entry, or the ray is finished and its slot is free again
 // Each ray still performs exactly the reference's depth-first sequence (same node test, same child order, same leaf
-// code, same stack discipline as trace_loop.hip.h), so results are bit-identical to the lane-per-ray kernel: built
-// with EXTRA=-DTRACE_WITH_POOL and selected with RTAMD_KERNEL=pool it passes the whole GPU suite.
+// code, same stack discipline as trace_loop.hip.h), so results are bit-identical to the lane-per-ray kernel (forced with
+// RTAMD_KERNEL=pool it passes the whole GPU suite; tests/test_gpu_properties.py compares the two on 4 M rays).
 //
-// EXPERIMENT, NOT THE DEFAULT.  Measured on MI355X (bomberman cbvh.leaf, 1 M random rays): 0.188 ms alone (lane kernel
+// USED FOR LARGE BATCHES ONLY (>= 2.5 M rays per launch, Device::tunePoolMinRays).  Measured on MI355X (bomberman cbvh.leaf, 1 M random rays): 0.188 ms alone (lane kernel
 // 0.176), 8.6 Grays/s with four batches in flight (10.3).  The phases do run fuller (lane utilisation 0.30 vs 0.27) but
 // the wave instructions per launch hardly change (44.0 M vs 46.0 M): a wave's instruction count is set by the number
 // of loop iterations it needs, and that is the step count of its DEEPEST ray (41 iterations for 488 rays per wave,
-// ~22 would do if every phase were full), not the amount of work.  Compaction inside a wave therefore does not pay;
-// what would is fewer, larger pools (rays of a whole workgroup or CU behind one set of queues), so that a deep ray
+// ~22 would do if every phase were full), not the amount of work.  Where the drain is amortised the fuller phases do
+// pay: 0.401 vs 0.423 ms at 4 M rays, 1.213 vs 1.365 ms at 16 M (67.7 vs 78.5 us per million rays).  The next step is
+// fewer, larger pools (rays of a whole workgroup or CU behind one set of queues), so that a deep ray
 // keeps one wavefront iterating instead of every wavefront one.
 #pragma once
 #include "trace_common.hip.h"

@@ -13,9 +13,7 @@
 // Scalar arithmetic of the fork is written without fused operations (the reference leaves contraction to its
 // compiler; this path is "parity unpinned").
 #include "trace_loop.hip.h"
-#ifdef TRACE_WITH_POOL // experimental second skeleton, see trace_pool.hip.h (make EXTRA=-DTRACE_WITH_POOL, env RTAMD_KERNEL=pool)
 #include "trace_pool.hip.h"
-#endif
 
 namespace rtamd {
 namespace dev {
@@ -545,7 +543,6 @@ template <int MODE, int LEVELS> struct CbvhLeaf
 
 template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t stream, uint32_t levels)
 {
-#ifdef TRACE_WITH_POOL
   if (p.poolKernel) switch (levels) {
     case 1: return launch_leaf_pool<CbvhLeaf<MODE, 1>, true>(p, stream);
     case 2: return launch_leaf_pool<CbvhLeaf<MODE, 2>, true>(p, stream);
@@ -554,7 +551,6 @@ template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t st
     case 5: return launch_leaf_pool<CbvhLeaf<MODE, 5>, true>(p, stream);
     default: return hipErrorInvalidValue;
     }
-#endif
   switch (levels) {
   case 1: return launch_leaf<CbvhLeaf<MODE, 1>, true>(p, stream);
   case 2: return launch_leaf<CbvhLeaf<MODE, 2>, true>(p, stream);
@@ -571,9 +567,7 @@ hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream)
 {
   switch (p.accel.kind) {
   case ACCEL_GRIDSOA:
-#ifdef TRACE_WITH_POOL
     if (p.poolKernel) return dev::launch_leaf_pool<dev::GridCellLeaf, true>(p, stream);
-#endif
     return dev::launch_leaf<dev::GridCellLeaf, true>(p, stream);
   case ACCEL_CBVH_BOX: return dev::launch_cbvh<dev::MODE_BOX>(p, stream, p.cbvhLevels);
   case ACCEL_CBVH_LEAF: return dev::launch_cbvh<dev::MODE_LEAF>(p, stream, p.cbvhLevels);

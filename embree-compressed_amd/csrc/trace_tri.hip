@@ -4,9 +4,7 @@
 //   block loop            kernels/geometry/intersector_iterators.h:32-36 (ArrayIntersector1)
 //   epilog / tie rules    kernels/geometry/intersector_epilog.h:226-307 (closest), :388-450 (any hit)
 #include "trace_loop.hip.h"
-#ifdef TRACE_WITH_POOL // experimental second skeleton, see trace_pool.hip.h (make EXTRA=-DTRACE_WITH_POOL, env RTAMD_KERNEL=pool)
 #include "trace_pool.hip.h"
-#endif
 
 namespace rtamd {
 namespace dev {
@@ -84,12 +82,10 @@ template <bool PLUECKER> struct TriLeaf
 hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream)
 {
   // Triangle4v <-> robust traversal, Triangle4 <-> fast traversal (bvh_intersector1_bvh8.cpp:27-29)
-#ifdef TRACE_WITH_POOL
   if (p.poolKernel) {
     if (p.accel.kind == ACCEL_TRI_PLUECKER) return dev::launch_leaf_pool<dev::TriLeaf<true>, true>(p, stream);
     return dev::launch_leaf_pool<dev::TriLeaf<false>, false>(p, stream);
   }
-#endif
   if (p.accel.kind == ACCEL_TRI_PLUECKER) return dev::launch_leaf<dev::TriLeaf<true>, true>(p, stream);
   return dev::launch_leaf<dev::TriLeaf<false>, false>(p, stream);
 }
