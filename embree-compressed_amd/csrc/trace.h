@@ -37,7 +37,14 @@ static const int TRACE_QUEUES = 64;       // work queues per launch (must equal 
 static const int TRACE_QUEUE_STRIDE = 32; // u32 words between two work-queue heads (128 B: one L2 line each)
 static const int TRACE_BLOCK = 256;     // 4 wavefronts per workgroup
 // ray-pool skeleton (trace_pool.hip.h): workgroup size, ray slots per wavefront, LDS stack entries per slot, workgroups per CU
-static const int TRACE_POOL_BLOCK = 128, TRACE_POOL_SLOTS = 128, TRACE_POOL_STACK = 8, TRACE_POOL_BLOCKS_PER_CU = 4;
+#ifndef TRACE_POOL_SLOTS_PER_WAVE
+#define TRACE_POOL_SLOTS_PER_WAVE 128
+#endif
+#ifndef TRACE_POOL_STACK_ENTRIES
+#define TRACE_POOL_STACK_ENTRIES 8
+#endif
+static const int TRACE_POOL_BLOCK = 128, TRACE_POOL_SLOTS = TRACE_POOL_SLOTS_PER_WAVE, TRACE_POOL_STACK = TRACE_POOL_STACK_ENTRIES;
+static const int TRACE_POOL_BLOCKS_PER_CU = 8; // upper bound of resident workgroups per CU (sizes the overflow area)
 #ifndef TRACE_LDS_STACK_ENTRIES
 #define TRACE_LDS_STACK_ENTRIES 16
 #endif

@@ -29,8 +29,17 @@
 namespace rtamd {
 namespace dev {
 
-static constexpr int POOL_R = 128;    // ray slots per wavefront
-static constexpr int POOL_STACK = 8;  // stack entries per slot kept in LDS (the rest goes to the HBM overflow area)
+#ifndef TRACE_POOL_SLOTS_PER_WAVE
+#define TRACE_POOL_SLOTS_PER_WAVE 128
+#endif
+#ifndef TRACE_POOL_STACK_ENTRIES
+#define TRACE_POOL_STACK_ENTRIES 8
+#endif
+// geometry sweep on MI355X (cbvh.leaf, 4 M rays alone / in flight): 128 slots x 8 entries 0.402 ms / 12.2 Grays/s;
+// 112 x 6: 0.414 / 11.6; 96 x 6: 0.435 / 11.1; 160 x 8: 0.441 / 10.9; 128 x 12: 0.461 / 10.2
+static constexpr int POOL_R = TRACE_POOL_SLOTS_PER_WAVE;     // ray slots per wavefront
+static constexpr int POOL_STACK = TRACE_POOL_STACK_ENTRIES;  // stack entries per slot kept in LDS (the rest goes to the HBM overflow area)
+static_assert(POOL_R == TRACE_POOL_SLOTS && POOL_STACK == TRACE_POOL_STACK, "trace.h sizes the overflow area from these");
 static constexpr int POOL_BLOCK = 128; // 2 wavefronts per workgroup: 39 KB of LDS each, four workgroups per CU
 static constexpr int POOL_WAVES = POOL_BLOCK / 64;
 // per-slot words: ray (8) + TravRay (7) + travFar + cur + sp + ray index
