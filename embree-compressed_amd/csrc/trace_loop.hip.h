@@ -66,6 +66,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   const uint32_t laneId = lane_rank(~0ull);
   uint32_t qCur = (blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6)) & (uint32_t)(TRACE_QUEUES - 1); // wave-uniform
   uint32_t poolNext = 0, poolEnd = 0; // wave-uniform: rays [poolNext, poolEnd) belong to this wave
+  // Staggered exhaustion: a quarter of the waves treats a queue as closed once 85 % of it are handed out, another quarter
+  // at 92 %, the rest drains it.  The waves then enter their drain (few deep rays, few active lanes) at different times
+  // instead of all at once; the SIMD slots of the early leavers are free for the other batches in flight.  Measured on
+  // cbvh.leaf, 1 M rays: +2.8 % with four batches in flight (11.17 vs 10.88 Grays/s over 40 steps), alone unchanged.
+  // (All waves at 100 %: baseline; half of the waves at 85 %: +2 % / -6 % alone; four levels 70..100 %: +1 % / -10 %.)
+  const uint32_t wIdx = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
+  const uint32_t stag = (wIdx & 3u) == 1u ? 85u : ((wIdx & 3u) == 3u ? 92u : 100u);
   bool exhausted = P.accel.root == REF_EMPTY;
 
   WorkCounters wc;
@@ -120,9 +127,18 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         for (;;) {
           const uint32_t qLo = min(qCur * perQ, P.count);
           const uint32_t qHi = min(qLo + perQ, P.count);
-          uint32_t base = 0;
-          if (laneId == 0u) base = atomicAdd(&queues[qCur * QUEUE_STRIDE], P.rayChunk);
-          base = __builtin_amdgcn_readfirstlane(base);
+          uint32_t base = 0xFFFFFFFFu;
+          bool open = true;
+          if (stag != 100u) { // this wave treats the queue as closed once `stag` percent of it are handed out
+            uint32_t pre = 0;
+            if (laneId == 0u) pre = __hip_atomic_load(&queues[qCur * QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pre = __builtin_amdgcn_readfirstlane(pre);
+            open = pre < (uint32_t)((uint64_t)(qHi - qLo) * stag / 100u);
+          }
+          if (open) {
+            if (laneId == 0u) base = atomicAdd(&queues[qCur * QUEUE_STRIDE], P.rayChunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+          }
           if (base < qHi - qLo) {
             if (COUNT) rtLastGrab = __builtin_amdgcn_s_memrealtime();
             poolNext = qLo + base;
@@ -133,7 +149,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           // ballot marks the queues that still have rays, take the next one cyclically after qCur
           const uint32_t myLo = min(laneId * perQ, P.count), myHi = min(myLo + perQ, P.count);
           const uint32_t head = __hip_atomic_load(&queues[laneId * QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t live = __ballot(laneId < (uint32_t)TRACE_QUEUES && head < myHi - myLo);
+          const uint64_t live = __ballot(laneId < (uint32_t)TRACE_QUEUES && head < (uint32_t)((uint64_t)(myHi - myLo) * stag / 100u));
           if (live == 0ull) { exhausted = true; break; }
           const uint64_t rot = (live >> qCur) | (qCur ? (live << (64u - qCur)) : 0ull); // bit k = queue (qCur+k)&63
           qCur = (qCur + (uint32_t)__builtin_ctzll(rot)) & (uint32_t)(TRACE_QUEUES - 1);
