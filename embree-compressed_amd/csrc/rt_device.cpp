@@ -52,7 +52,7 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_LEAF_BATCH")) tuneLeafBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_REFILL_BATCH")) tuneRefillBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_KERNEL")) tunePoolKernel = strcmp(env, "pool") == 0 ? 1u : (strcmp(env, "lane") == 0 ? 0u : 2u);
-  if (const char* env = getenv("RTAMD_BLOCKS_PER_CU")) tuneBlocksPerCU = (uint32_t)std::max(0, atoi(env));
+  if (const char* env = getenv("RTAMD_BLOCKS_PER_CU")) { tuneBlocksPerCU = (uint32_t)std::max(0, atoi(env)); tuneBlocksAuto = false; }
   if (cfg) parse(cfg);
   if (gpu == -1) {
     // "gpu=none": host-only object model (build + inspect accels); every trace call raises
@@ -154,18 +154,21 @@ void Device::ensureStaging(size_t bytes)
   stageBytes = want;
 }
 
-Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded)
+Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther)
 {
   std::lock_guard<std::mutex> lock(ctxMutex);
+  unsigned others = 0;
   // first context whose last kernel has finished (back-to-back batches on one stream then cycle through two or three
   // contexts, and only those get a spill area); all busy: take the next one in turn and wait for it on the stream
   LaunchCtx* pick = nullptr;
   for (LaunchCtx& k : launchCtx) {
-    if (!k.used) { pick = &k; break; }
+    if (!k.used) { if (!pick) pick = &k; continue; }
     const hipError_t q = hipEventQuery(k.done);
-    if (q == hipSuccess) { k.used = false; pick = &k; break; }
+    if (q == hipSuccess) { k.used = false; if (!pick) pick = &k; continue; }
     if (q != hipErrorNotReady) HIP_CHECK(q);
+    if (k.stream != stream) others++;
   }
+  if (busyOther) *busyOther = others;
   (void)hipGetLastError(); // hipErrorNotReady is not an error
   LaunchCtx& c = pick ? *pick : launchCtx[nextCtx++ % NUM_LAUNCH_CTX];
   if (spillBytesNeeded > c.spillBytes) {
@@ -184,6 +187,7 @@ Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded)
   }
   if (c.used) HIP_CHECK(hipStreamWaitEvent(stream, c.done, 0));
   c.used = true;
+  c.stream = stream;
   return c;
 }
 

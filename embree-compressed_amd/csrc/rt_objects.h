@@ -59,6 +59,7 @@ struct Device : RefCounted
     size_t spillBytes = 0;
     hipEvent_t done = nullptr;
     bool used = false;
+    hipStream_t stream = nullptr; // stream of the launch that last used this context
   };
   static const int NUM_LAUNCH_CTX = 8;
   LaunchCtx launchCtx[NUM_LAUNCH_CTX];
@@ -108,7 +109,9 @@ struct Device : RefCounted
   RTCError takeError();
   void useDevice() const; // hipSetDevice(gpu) for the calling thread
   void ensureStaging(size_t bytes);
-  LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded); // picks the next context, makes `stream` wait for its previous user
+  // picks the next context, makes `stream` wait for its previous user; *busyOther = launches still running on OTHER streams
+  LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther = nullptr);
+  bool tuneBlocksAuto = true; // no RTAMD_BLOCKS_PER_CU given: 2 workgroups per CU, 1 when >= 2 batches run on other streams
   void memoryMonitor(ssize_t bytes, bool post);
 };
 

@@ -49,14 +49,18 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
     p.spillDepth = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
     spillBytes = (size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u;
   }
-  Device::LaunchCtx& ctx = dev->acquireLaunchCtx(spillBytes);
+  unsigned busyOther = 0;
+  Device::LaunchCtx& ctx = dev->acquireLaunchCtx(spillBytes, &busyOther);
   p.spill = ctx.spill;
   p.counters = dCounters;
   p.cbvhLevels = s->compressionLevel;
   p.numCUs = (uint32_t)dev->numCUs;
   p.rayChunk = dev->tuneChunk;
   p.leafBatch = dev->tuneLeafBatch;
-  p.blocksPerCU = dev->tuneBlocksPerCU;
+  // A batch alone on the chip is fastest with two workgroups per CU; when two or more batches are running on other
+  // streams a leaner grid is better: every wave pays its deepest ray's iterations, so fewer waves per batch waste fewer
+  // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
+  p.blocksPerCU = dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : 2u) : dev->tuneBlocksPerCU;
   p.refillBatch = dev->tuneRefillBatch;
   p.queues = (uint32_t*)ctx.queues;
   p.exclOffsets = exclOffsets;
