@@ -158,6 +158,7 @@ Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* b
 {
   std::lock_guard<std::mutex> lock(ctxMutex);
   unsigned others = 0;
+  hipStream_t otherStreams[NUM_LAUNCH_CTX];
   // first context whose last kernel has finished (back-to-back batches on one stream then cycle through two or three
   // contexts, and only those get a spill area); all busy: take the next one in turn and wait for it on the stream
   LaunchCtx* pick = nullptr;
@@ -166,7 +167,11 @@ Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* b
     const hipError_t q = hipEventQuery(k.done);
     if (q == hipSuccess) { k.used = false; if (!pick) pick = &k; continue; }
     if (q != hipErrorNotReady) HIP_CHECK(q);
-    if (k.stream != stream) others++;
+    if (k.stream != stream) { // count every OTHER stream once: queued launches on one stream run one after the other
+      bool seen = false;
+      for (unsigned i = 0; i < others; i++) seen |= otherStreams[i] == k.stream;
+      if (!seen) otherStreams[others++] = k.stream;
+    }
   }
   if (busyOther) *busyOther = others;
   (void)hipGetLastError(); // hipErrorNotReady is not an error

@@ -109,7 +109,7 @@ struct Device : RefCounted
   RTCError takeError();
   void useDevice() const; // hipSetDevice(gpu) for the calling thread
   void ensureStaging(size_t bytes);
-  // picks the next context, makes `stream` wait for its previous user; *busyOther = launches still running on OTHER streams
+  // picks the next context, makes `stream` wait for its previous user; *busyOther = OTHER streams with unfinished launches
   LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther = nullptr);
   bool tuneBlocksAuto = true; // no RTAMD_BLOCKS_PER_CU given: 2 workgroups per CU, 1 when >= 2 batches run on other streams
   void memoryMonitor(ssize_t bytes, bool post);

@@ -69,7 +69,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   // Staggered exhaustion: a quarter of the waves treats a queue as closed once 85 % of it are handed out, another quarter
   // at 92 %, the rest drains it.  The waves then enter their drain (few deep rays, few active lanes) at different times
   // instead of all at once; the SIMD slots of the early leavers are free for the other batches in flight.  Measured on
-  // cbvh.leaf, 1 M rays: +2.8 % with four batches in flight (11.17 vs 10.88 Grays/s over 40 steps), alone unchanged.
+  // cbvh.leaf, 1 M rays: +2.8 % with four batches in flight (11.17 vs 10.88 Grays/s over 40 steps), -1 % with two or three,
+  // alone unchanged.
   // (All waves at 100 %: baseline; half of the waves at 85 %: +2 % / -6 % alone; four levels 70..100 %: +1 % / -10 %.)
   const uint32_t wIdx = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
   const uint32_t stag = (wIdx & 3u) == 1u ? 85u : ((wIdx & 3u) == 3u ? 92u : 100u);
