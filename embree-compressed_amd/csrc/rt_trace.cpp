@@ -7,8 +7,8 @@ namespace rtamd {
 
 uint32_t trace_grid_blocks(uint32_t count, int numCUs)
 {
-  // 32 KiB of LDS stack per workgroup -> 5 resident workgroups (20 waves) per CU
-  const uint32_t resident = (uint32_t)numCUs * 5u;
+  // upper bound of the resident set: 20 waves per CU
+  const uint32_t resident = (uint32_t)numCUs * 5u * (256u / TRACE_BLOCK);
   const uint32_t need = (count + TRACE_BLOCK - 1) / TRACE_BLOCK;
   return need < resident ? (need ? need : 1u) : resident;
 }
@@ -60,7 +60,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   // A batch alone on the chip is fastest with two workgroups per CU; when two or more batches are running on other
   // streams a leaner grid is better: every wave pays its deepest ray's iterations, so fewer waves per batch waste fewer
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
-  p.blocksPerCU = dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : 2u) : dev->tuneBlocksPerCU;
+  p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : 2u) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.refillBatch = dev->tuneRefillBatch;
   p.queues = (uint32_t*)ctx.queues;
   p.exclOffsets = exclOffsets;

@@ -35,7 +35,10 @@ struct LaunchParams
 
 static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)
 static const int TRACE_QUEUE_STRIDE = 32; // u32 words between two work-queue heads (128 B: one L2 line each)
-static const int TRACE_BLOCK = 256;     // 4 wavefronts per workgroup
+#ifndef TRACE_BLOCK_THREADS
+#define TRACE_BLOCK_THREADS 256
+#endif
+static const int TRACE_BLOCK = TRACE_BLOCK_THREADS; // threads per workgroup of the lane-per-ray kernel (4 wavefronts)
 // ray-pool skeleton (trace_pool.hip.h): workgroup size, ray slots per wavefront, LDS stack entries per slot, workgroups per CU
 #ifndef TRACE_POOL_SLOTS_PER_WAVE
 #define TRACE_POOL_SLOTS_PER_WAVE 128
