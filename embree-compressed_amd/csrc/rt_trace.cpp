@@ -62,6 +62,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : 2u) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.refillBatch = dev->tuneRefillBatch;
+  p.octMax = dev->tuneOctMax;
   p.queues = (uint32_t*)ctx.queues;
   p.exclOffsets = exclOffsets;
   p.exclPairs = exclPairs;

@@ -49,8 +49,28 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) // number of set bi
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// ---- child-parallel ("octet") node step ----------------------------------------------------------------------
+// When at most TRACE_OCT_MAX lanes of a wave have node work, the node step is not run lane-per-ray (one lane tests the
+// 8 children of its node one after the other: ~600 dependent instructions whatever the number of busy lanes) but with 8
+// lanes per ray: lane 8g+k tests child k of the node of the g-th ray.  The rays' node-test constants travel through a
+// small LDS exchange area, the visiting order of the hit children comes from seven DPP compares inside the octet, the
+// stacked children are written straight into the owning lane's LDS stack column.  Arithmetic, child order and stack
+// contents are exactly those of the lane-per-ray step below (same TravRay functions, same tie rule), so results do not
+// change; what changes is the critical path of the few deep rays that bound a batch's drain (measured on MI355X: a lone
+// ray needs ~1.1 us per lane-per-ray node step) and the instructions those nearly empty waves take from everybody else.
+#ifndef TRACE_OCT_MAX
+#define TRACE_OCT_MAX 32
+#endif
+static constexpr int OCT_ROWS = TRACE_OCT_MAX > 0 ? TRACE_OCT_MAX : 1; // rays per wave the exchange area holds
+static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner thread + pad
+enum : int { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_XOR3 = 0x1B, DPP_HALF_MIRROR = 0x141 }; // quad_perm / row_half_mirror
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
+{
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK])
+__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK], float (*octX)[OCT_WORDS])
 {
   const uint32_t tid = threadIdx.x;
   const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
@@ -191,7 +211,103 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
 
     // ---- inner node step ---------------------------------------------------------------------------------
     const bool atNode = st == ST_ACTIVE && !(cur & REF_LEAF);
-    if (atNode) {
+    const uint64_t nodeMask = __ballot(atNode);
+    const uint32_t nNode = (uint32_t)__popcll(nodeMask);
+    // the octet step writes LDS stack slots only: a ray whose push could reach the overflow area takes the other path
+    const bool useOct = TRACE_OCT_MAX > 0 && nNode != 0u && nNode <= min((uint32_t)TRACE_OCT_MAX, P.octMax) &&
+                        __ballot(atNode && sp + 7u > (uint32_t)TRACE_LDS_STACK) == 0ull;
+    if (useOct) {
+      {
+        // lane-constant values of this block (lane index, octet row, tie constants) are derived from an opaque copy of the
+        // lane id: otherwise the compiler hoists them out of the traversal loop and keeps ~12 registers alive through the
+        // lane-per-ray node step and the leaf code, which are at the register limit already (measured: 64-80 B of scratch)
+        uint32_t lid = laneId;
+        asm volatile("" : "+v"(lid));
+        const uint32_t myRow = lane_rank(nodeMask);
+        if (atNode) {
+          if (COUNT) wc.nodes++;
+          float* x = octX[myRow];
+          tr.store(x, 1);
+          x[7] = travFar;
+          x[8] = __uint_as_float(cur);
+          x[9] = __uint_as_float(sp);
+          x[10] = __uint_as_float(tid);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t k = lid & 7u;
+        for (uint32_t base = 0; base < nNode; base += 8u) {
+          const uint32_t row = base + (lid >> 3);
+          const bool valid = row < nNode;
+          uint32_t dist = 0xFFFFFFFFu, cref = REF_EMPTY, oSp = 0, oTid = 0;
+          bool h = false;
+          if (valid) {
+            const float* x = octX[row];
+            TravRay<ROBUST> t;
+            t.load(x, 1);
+            const float oFar = x[7];
+            const uint32_t oCur = __float_as_uint(x[8]);
+            oSp = __float_as_uint(x[9]);
+            oTid = __float_as_uint(x[10]);
+            const unsigned char* nb = (const unsigned char*)(nodes + oCur);
+            const uint4 n0 = *(const uint4*)nb;
+            cref = ((const uint32_t*)nb)[4u + k];
+            const bool ngx = t.negx(), ngy = t.negy(), ngz = t.negz();
+            // plane bytes: lower[0..7] at 48/64/80, upper[0..7] eight bytes further (x / y / z)
+            const uint32_t qnx = nb[48u + (ngx ? 8u : 0u) + k], qfx = nb[48u + (ngx ? 0u : 8u) + k];
+            const uint32_t qny = nb[64u + (ngy ? 8u : 0u) + k], qfy = nb[64u + (ngy ? 0u : 8u) + k];
+            const uint32_t qnz = nb[80u + (ngz ? 8u : 0u) + k], qfz = nb[80u + (ngz ? 0u : 8u) + k];
+            const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+            const float sx = __uint_as_float((n0.w & 0xffu) << 23);
+            const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
+            const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+            const float npx = madd((float)qnx, sx, ox), npy = madd((float)qny, sy, oy), npz = madd((float)qnz, sz, oz);
+            const float fpx = madd((float)qfx, sx, ox), fpy = madd((float)qfy, sy, oy), fpz = madd((float)qfz, sz, oz);
+            const float tN = fmaxf(t.nearT(npx, npy, npz), t.tnear);
+            const float tF = fminf(t.farT(fpx, fpy, fpz), oFar);
+            h = (tN <= tF) & (cref != REF_EMPTY);
+            dist = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+          }
+          const uint32_t mask8 = (uint32_t)(__ballot(h) >> (lid & 56u)) & 0xffu;
+          const uint32_t nhit = (uint32_t)__popc(mask8);
+          uint32_t rank;
+          if (OCCLUDED) rank = (uint32_t)__popc(mask8 >> (k + 1u)); // traverseAnyHit: highest index first
+          else {
+            // children visited before this one: strictly nearer, or equally near with a higher index (the tie rule of
+            // the lane-per-ray step); non-hit lanes carry 0xFFFFFFFF and never count.  The partner of lane k under
+            // "xor x" is child k^x; whether that index is higher is a per-lane constant.
+            const uint32_t m = dpp_u32<DPP_HALF_MIRROR>(dist); // child k^7
+            const uint32_t d1 = dpp_u32<DPP_XOR1>(dist), d2 = dpp_u32<DPP_XOR2>(dist), d3 = dpp_u32<DPP_XOR3>(dist);
+            const uint32_t d4 = dpp_u32<DPP_XOR3>(m), d5 = dpp_u32<DPP_XOR2>(m), d6 = dpp_u32<DPP_XOR1>(m);
+            rank = 0;
+            rank += d1 < dist + ((k ^ 1u) > k ? 1u : 0u) ? 1u : 0u;
+            rank += d2 < dist + ((k ^ 2u) > k ? 1u : 0u) ? 1u : 0u;
+            rank += d3 < dist + ((k ^ 3u) > k ? 1u : 0u) ? 1u : 0u;
+            rank += d4 < dist + ((k ^ 4u) > k ? 1u : 0u) ? 1u : 0u;
+            rank += d5 < dist + ((k ^ 5u) > k ? 1u : 0u) ? 1u : 0u;
+            rank += d6 < dist + ((k ^ 6u) > k ? 1u : 0u) ? 1u : 0u;
+            rank += m < dist + ((k ^ 7u) > k ? 1u : 0u) ? 1u : 0u;
+          }
+          if (valid) {
+            const uint32_t top = oSp + nhit - 1u; // nhit == 0: unused
+            if (h) {
+              if (rank == 0u) {
+                octX[row][8] = __uint_as_float(cref);
+                octX[row][9] = __uint_as_float(top);
+              } else ldsStack[top - rank][oTid] = make_uint2(cref, dist);
+            } else if (nhit == 0u && k == 0u) octX[row][8] = __uint_as_float(REF_EMPTY);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (atNode) {
+          cur = __float_as_uint(octX[myRow][8]);
+          sp = __float_as_uint(octX[myRow][9]);
+          if (cur == REF_EMPTY) st |= ST_POP;
+        }
+      }
+    }
+    else if (atNode) {
       if (COUNT) wc.nodes++;
       const uint4* np = (const uint4*)(nodes + cur);
       const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4], n5 = np[5];
@@ -366,8 +482,9 @@ template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
 __global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES_PER_SIMD) void trace_kernel(LaunchParams P)
 {
   __shared__ uint2 ldsStack[TRACE_LDS_STACK + 1][TRACE_BLOCK]; // + one scratch row for the branch-free pushes
+  __shared__ __attribute__((aligned(16))) float octX[TRACE_BLOCK / 64][OCT_ROWS][OCT_WORDS]; // octet node step: per-wave exchange rows
   Leaf::prepare();
-  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack);
+  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack, octX[threadIdx.x >> 6]);
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT>

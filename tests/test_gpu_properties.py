@@ -85,3 +85,43 @@ def test_full_size_properties(rtc, bomberman, kind):
         assert torch.equal(occ[untouched], rays[:, :48][untouched])
     sc.release()
     dev.release()
+
+
+@pytest.mark.parametrize("kind", ["tri", "bvh4.compressed.leaf", "default"])
+def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
+    """The child-parallel (octet) node step (trace_loop.hip.h), taken when few lanes of a wave have node work, against the
+    lane-per-ray node step, and the instrumented kernel twin against the plain one: identical ray records, byte for byte,
+    over repeated runs (the ray-to-wave assignment is dynamic, so every run mixes the lanes differently).  The twin's hit
+    counter must equal the number of hit records."""
+    import torch
+
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    verts = bomberman[0]
+    n = 1_000_000
+    rays = torch.from_numpy(rg.make_random_rays(n, verts.min(0), verts.max(0), seed=7)).cuda()
+    monkeypatch.setenv("RTAMD_KERNEL", "lane")
+    monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
+    dev0, sc0 = _scene(rtc, bomberman, kind)
+    dev0.set_stream(torch.cuda.current_stream().cuda_stream)  # clones (torch's stream) and traces are then stream-ordered
+    ref = rays.clone()
+    sc0.intersect1M(ref)
+    dev0.synchronize()
+    hits = int((ref.view(torch.int32)[:, 18] != -1).sum().item())
+    for octmax in ("0", "8", "16", "32"):
+        monkeypatch.setenv("RTAMD_OCT_MAX", octmax)
+        dev, sc = _scene(rtc, bomberman, kind)
+        dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        for rep in range(2):
+            got = rays.clone()
+            sc.intersect1M(got)
+            dev.synchronize()
+            assert torch.equal(got, ref), f"{kind}: octet threshold {octmax}, plain kernel, run {rep}"
+            got = rays.clone()
+            cnt = sc.intersect1M_counted(got)
+            dev.synchronize()
+            assert torch.equal(got, ref), f"{kind}: octet threshold {octmax}, counted twin, run {rep}"
+            assert cnt["hits"] == hits
+        sc.release()
+        dev.release()
+    sc0.release()
+    dev0.release()
