@@ -62,7 +62,13 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) // number of set bi
 #define TRACE_OCT_MAX 32
 #endif
 static constexpr int OCT_ROWS = TRACE_OCT_MAX > 0 ? TRACE_OCT_MAX : 1; // rays per wave the exchange area holds
-static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner thread + pad
+static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner thread + direction signs
+#ifndef TRACE_OCT_PIPE
+#define TRACE_OCT_PIPE 1
+#endif
+// passes of 8 rays whose node loads are in flight together.  Measured: 2 or 4 make the register allocator spill 136-168 bytes
+// per lane in the subdivision kernels (the whole loop then runs 20 % slower), so one pass at a time it is
+static constexpr int OCT_PIPE = TRACE_OCT_PIPE;
 enum : int { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_XOR3 = 0x1B, DPP_HALF_MIRROR = 0x141 }; // quad_perm / row_half_mirror
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
@@ -232,70 +238,90 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           x[8] = __uint_as_float(cur);
           x[9] = __uint_as_float(sp);
           x[10] = __uint_as_float(tid);
+          x[11] = __uint_as_float((tr.negx() ? 1u : 0u) | (tr.negy() ? 2u : 0u) | (tr.negz() ? 4u : 0u));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t k = lid & 7u;
-        for (uint32_t base = 0; base < nNode; base += 8u) {
-          const uint32_t row = base + (lid >> 3);
-          const bool valid = row < nNode;
-          uint32_t dist = 0xFFFFFFFFu, cref = REF_EMPTY, oSp = 0, oTid = 0;
-          bool h = false;
-          if (valid) {
-            const float* x = octX[row];
-            TravRay<ROBUST> t;
-            t.load(x, 1);
-            const float oFar = x[7];
-            const uint32_t oCur = __float_as_uint(x[8]);
-            oSp = __float_as_uint(x[9]);
-            oTid = __float_as_uint(x[10]);
-            const unsigned char* nb = (const unsigned char*)(nodes + oCur);
-            const uint4 n0 = *(const uint4*)nb;
-            cref = ((const uint32_t*)nb)[4u + k];
-            const bool ngx = t.negx(), ngy = t.negy(), ngz = t.negz();
-            // plane bytes: lower[0..7] at 48/64/80, upper[0..7] eight bytes further (x / y / z)
-            const uint32_t qnx = nb[48u + (ngx ? 8u : 0u) + k], qfx = nb[48u + (ngx ? 0u : 8u) + k];
-            const uint32_t qny = nb[64u + (ngy ? 8u : 0u) + k], qfy = nb[64u + (ngy ? 0u : 8u) + k];
-            const uint32_t qnz = nb[80u + (ngz ? 8u : 0u) + k], qfz = nb[80u + (ngz ? 0u : 8u) + k];
-            const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
-            const float sx = __uint_as_float((n0.w & 0xffu) << 23);
-            const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
-            const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
-            const float npx = madd((float)qnx, sx, ox), npy = madd((float)qny, sy, oy), npz = madd((float)qnz, sz, oz);
-            const float fpx = madd((float)qfx, sx, ox), fpy = madd((float)qfy, sy, oy), fpz = madd((float)qfz, sz, oz);
-            const float tN = fmaxf(t.nearT(npx, npy, npz), t.tnear);
-            const float tF = fminf(t.farT(fpx, fpy, fpz), oFar);
-            h = (tN <= tF) & (cref != REF_EMPTY);
-            dist = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+        // Passes of 8 rays, OCT_PIPE passes at a time: first the node data of all of them is requested (one memory round
+        // trip for the group instead of one per pass), then each pass is evaluated.  Rows past the last ray repeat the
+        // last ray's loads and are masked out of the result.
+        for (uint32_t base0 = 0; base0 < nNode; base0 += 8u * OCT_PIPE) {
+          uint4 n0A[OCT_PIPE];
+          uint32_t crefA[OCT_PIPE], qnA[OCT_PIPE][3], qfA[OCT_PIPE][3];
+#pragma unroll
+          for (int pp = 0; pp < OCT_PIPE; pp++) {
+            if (base0 + 8u * pp < nNode) { // wave-uniform
+              const uint32_t rowc = min(base0 + 8u * pp + (lid >> 3), nNode - 1u);
+              const float* x = octX[rowc];
+              const uint32_t oCur = __float_as_uint(x[8]);
+              const uint32_t sg = __float_as_uint(x[11]); // bit a: direction component a is negative
+              const unsigned char* nb = (const unsigned char*)(nodes + oCur);
+              n0A[pp] = *(const uint4*)nb;
+              crefA[pp] = ((const uint32_t*)nb)[4u + k];
+              // plane bytes: lower[0..7] at 48/64/80, upper[0..7] eight bytes further (x / y / z)
+#pragma unroll
+              for (int a = 0; a < 3; a++) {
+                const uint32_t neg = (sg >> a) & 1u;
+                qnA[pp][a] = nb[48u + 16u * a + 8u * neg + k];
+                qfA[pp][a] = nb[56u + 16u * a - 8u * neg + k];
+              }
+            }
           }
-          const uint32_t mask8 = (uint32_t)(__ballot(h) >> (lid & 56u)) & 0xffu;
-          const uint32_t nhit = (uint32_t)__popc(mask8);
-          uint32_t rank;
-          if (OCCLUDED) rank = (uint32_t)__popc(mask8 >> (k + 1u)); // traverseAnyHit: highest index first
-          else {
-            // children visited before this one: strictly nearer, or equally near with a higher index (the tie rule of
-            // the lane-per-ray step); non-hit lanes carry 0xFFFFFFFF and never count.  The partner of lane k under
-            // "xor x" is child k^x; whether that index is higher is a per-lane constant.
-            const uint32_t m = dpp_u32<DPP_HALF_MIRROR>(dist); // child k^7
-            const uint32_t d1 = dpp_u32<DPP_XOR1>(dist), d2 = dpp_u32<DPP_XOR2>(dist), d3 = dpp_u32<DPP_XOR3>(dist);
-            const uint32_t d4 = dpp_u32<DPP_XOR3>(m), d5 = dpp_u32<DPP_XOR2>(m), d6 = dpp_u32<DPP_XOR1>(m);
-            rank = 0;
-            rank += d1 < dist + ((k ^ 1u) > k ? 1u : 0u) ? 1u : 0u;
-            rank += d2 < dist + ((k ^ 2u) > k ? 1u : 0u) ? 1u : 0u;
-            rank += d3 < dist + ((k ^ 3u) > k ? 1u : 0u) ? 1u : 0u;
-            rank += d4 < dist + ((k ^ 4u) > k ? 1u : 0u) ? 1u : 0u;
-            rank += d5 < dist + ((k ^ 5u) > k ? 1u : 0u) ? 1u : 0u;
-            rank += d6 < dist + ((k ^ 6u) > k ? 1u : 0u) ? 1u : 0u;
-            rank += m < dist + ((k ^ 7u) > k ? 1u : 0u) ? 1u : 0u;
-          }
-          if (valid) {
-            const uint32_t top = oSp + nhit - 1u; // nhit == 0: unused
-            if (h) {
-              if (rank == 0u) {
-                octX[row][8] = __uint_as_float(cref);
-                octX[row][9] = __uint_as_float(top);
-              } else ldsStack[top - rank][oTid] = make_uint2(cref, dist);
-            } else if (nhit == 0u && k == 0u) octX[row][8] = __uint_as_float(REF_EMPTY);
+#pragma unroll
+          for (int pp = 0; pp < OCT_PIPE; pp++) {
+            if (base0 + 8u * pp < nNode) {
+              const uint32_t row = base0 + 8u * pp + (lid >> 3);
+              const bool valid = row < nNode;
+              const uint32_t rowc = min(row, nNode - 1u);
+              const float* x = octX[rowc];
+              TravRay<ROBUST> t;
+              t.load(x, 1);
+              const float oFar = x[7];
+              const uint32_t oSp = __float_as_uint(x[9]);
+              const uint32_t oTid = __float_as_uint(x[10]);
+              const uint4 n0 = n0A[pp];
+              const uint32_t cref = crefA[pp];
+              const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+              const float sx = __uint_as_float((n0.w & 0xffu) << 23);
+              const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
+              const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+              const float npx = madd((float)qnA[pp][0], sx, ox), npy = madd((float)qnA[pp][1], sy, oy), npz = madd((float)qnA[pp][2], sz, oz);
+              const float fpx = madd((float)qfA[pp][0], sx, ox), fpy = madd((float)qfA[pp][1], sy, oy), fpz = madd((float)qfA[pp][2], sz, oz);
+              const float tN = fmaxf(t.nearT(npx, npy, npz), t.tnear);
+              const float tF = fminf(t.farT(fpx, fpy, fpz), oFar);
+              const bool h = valid & (tN <= tF) & (cref != REF_EMPTY);
+              const uint32_t dist = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+              const uint32_t mask8 = (uint32_t)(__ballot(h) >> (lid & 56u)) & 0xffu;
+              const uint32_t nhit = (uint32_t)__popc(mask8);
+              uint32_t rank;
+              if (OCCLUDED) rank = (uint32_t)__popc(mask8 >> (k + 1u)); // traverseAnyHit: highest index first
+              else {
+                // children visited before this one: strictly nearer, or equally near with a higher index (the tie rule
+                // of the lane-per-ray step); non-hit lanes carry 0xFFFFFFFF and never count.  The partner of lane k under
+                // "xor x" is child k^x; whether that index is higher is a per-lane constant.
+                const uint32_t m = dpp_u32<DPP_HALF_MIRROR>(dist); // child k^7
+                const uint32_t d1 = dpp_u32<DPP_XOR1>(dist), d2 = dpp_u32<DPP_XOR2>(dist), d3 = dpp_u32<DPP_XOR3>(dist);
+                const uint32_t d4 = dpp_u32<DPP_XOR3>(m), d5 = dpp_u32<DPP_XOR2>(m), d6 = dpp_u32<DPP_XOR1>(m);
+                rank = 0;
+                rank += d1 < dist + ((k ^ 1u) > k ? 1u : 0u) ? 1u : 0u;
+                rank += d2 < dist + ((k ^ 2u) > k ? 1u : 0u) ? 1u : 0u;
+                rank += d3 < dist + ((k ^ 3u) > k ? 1u : 0u) ? 1u : 0u;
+                rank += d4 < dist + ((k ^ 4u) > k ? 1u : 0u) ? 1u : 0u;
+                rank += d5 < dist + ((k ^ 5u) > k ? 1u : 0u) ? 1u : 0u;
+                rank += d6 < dist + ((k ^ 6u) > k ? 1u : 0u) ? 1u : 0u;
+                rank += m < dist + ((k ^ 7u) > k ? 1u : 0u) ? 1u : 0u;
+              }
+              if (valid) {
+                const uint32_t top = oSp + nhit - 1u; // nhit == 0: unused
+                if (h) {
+                  if (rank == 0u) {
+                    octX[row][8] = __uint_as_float(cref);
+                    octX[row][9] = __uint_as_float(top);
+                  } else ldsStack[top - rank][oTid] = make_uint2(cref, dist);
+                } else if (nhit == 0u && k == 0u) octX[row][8] = __uint_as_float(REF_EMPTY);
+              }
+            }
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
