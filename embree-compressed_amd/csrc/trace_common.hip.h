@@ -146,6 +146,7 @@ __device__ __forceinline__ float q2f(uint32_t w, int k) { return (float)((w >> (
 struct TriHit
 {
   float t, u, v, ngx, ngy, ngz;
+  float Ts, absDen; // operands of the depth test `Ts <= absDen * tfar` (the octet leaf step re-evaluates it with a newer tfar)
 };
 
 // Pluecker, watertight, no backface culling (triangle_intersector_pluecker.h:79-132).
@@ -184,6 +185,7 @@ __device__ __forceinline__ bool pluecker(const RayState& r, const float4 A, cons
   const float tn = dot3(v0x, v0y, v0z, ngx, ngy, ngz);
   const float T = tn + tn;
   const float Ts = xorf(T, sgnDen);
+  h.Ts = Ts; h.absDen = absDen;
   if (!(absDen * r.tnear < Ts)) return false;
   if (!(Ts <= absDen * tfarBlock)) return false;
   if (!(den != 0.0f)) return false;
@@ -214,6 +216,7 @@ __device__ __forceinline__ bool moeller(const RayState& r, const float4 A, const
   const float V = xorf(dot3(rx, ry, rz, B.x, B.y, B.z), sgnDen);
   if (!((den != 0.0f) & (U >= 0.0f) & (V >= 0.0f) & (U + V <= absDen))) return false;
   const float T = xorf(dot3(ngx, ngy, ngz, cx, cy, cz), sgnDen);
+  h.Ts = T; h.absDen = absDen;
   if (!((absDen * r.tnear < T) & (T <= absDen * tfarBlock))) return false;
   const float rcpAbsDen = 1.0f / absDen;
   h.t = T * rcpAbsDen;

@@ -434,7 +434,52 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     const uint64_t leafMask = __ballot(atLeafNow);
     if (leafMask != 0ull) {
       const bool nodeWork = __ballot(atNodeNext) != 0ull;
-      if (__popcll(leafMask) >= (int)P.leafBatch || !nodeWork) {
+      const uint32_t nLeaf = (uint32_t)__popcll(leafMask);
+      bool leafDone = false;
+      if constexpr (Leaf::OCTET) {
+        // Child-parallel leaf step (leaves whose primitives map onto the 8 lanes of an octet): lane 8g+k tests primitive k
+        // of the leaf of the g-th waiting ray.  A pass of 8 rays costs about a fifth of the lane-per-ray leaf code and runs
+        // on full wavefronts, so the lanes need not wait for P.leafBatch companions: 8 waiting rays are enough.
+        if (P.octLeaf != 0u && Leaf::octet_ok(P) && nLeaf <= (uint32_t)OCT_ROWS && (nLeaf >= P.octLeaf || !nodeWork)) {
+          leafDone = true;
+          if (COUNT) nLeafPhase++;
+          uint32_t lid = laneId;
+          asm volatile("" : "+v"(lid)); // see the node step: keeps the lane constants of this block out of the loop's live set
+          const uint32_t myRow = lane_rank(leafMask);
+          if (atLeafNow) {
+            if (COUNT) wc.leaves++;
+            float* x = octX[myRow];
+            x[0] = r.ox; x[1] = r.oy; x[2] = r.oz; x[3] = r.tnear;
+            x[4] = r.dx; x[5] = r.dy; x[6] = r.dz; x[7] = r.tfar;
+            x[8] = __uint_as_float(cur);
+            x[9] = __uint_as_float(0u); // result flag
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          for (uint32_t base = 0; base < nLeaf; base += 8u) {
+            const uint32_t row = base + (lid >> 3);
+            Leaf::template octet_pass<OCCLUDED, COUNT>(P, octX[min(row, nLeaf - 1u)], row < nLeaf, lid, wc);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (atLeafNow) {
+            const float* x = octX[myRow];
+            if (__float_as_uint(x[9]) != 0u) {
+              r.hit = 1u;
+              if (OCCLUDED) {
+                r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
+                sp = 0;           // any hit found: terminate this ray
+              } else {
+                r.tfar = x[0]; r.ngx = x[1]; r.ngy = x[2]; r.ngz = x[3]; r.u = x[4]; r.v = x[5];
+                r.geomID = __float_as_uint(x[6]); r.primID = __float_as_uint(x[7]);
+              }
+            }
+            travFar = OCCLUDED ? travFar : r.tfar; // tray.tfar = ray.tfar (bvh_intersector1.cpp:117)
+            st |= ST_POP;
+          }
+        }
+      }
+      if (!leafDone && (nLeaf >= P.leafBatch || !nodeWork)) {
         if (COUNT) nLeafPhase++;
         if (atLeafNow) {
           if (COUNT) wc.leaves++;

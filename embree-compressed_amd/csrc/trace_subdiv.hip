@@ -70,7 +70,62 @@ __device__ __forceinline__ bool pluecker_rel(const RayState& r, const RelV a, co
 
 struct GridCellLeaf
 {
+  static constexpr bool OCTET = true;
+  static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
   static __device__ __forceinline__ void prepare() {}
+
+  // Child-parallel form (trace_loop.hip.h): lane 8g+k tests triangle k of the cell of the ray in exchange row `x`
+  // (words 0..7 = org, tnear, dir, tfar; word 8 = leaf ref).  Same vertex differences, same Pluecker test against the tfar
+  // at cell entry, same winner (minimum t, lowest triangle on ties, select_min vfloat4_sse2.h:654-659) as intersect()
+  // below; the winning lane maps uv and writes the hit into the row (words 0..7 = t, Ng, u, v, geomID, primID; word 9 = 1).
+  template <bool OCCLUDED, bool COUNT>
+  static __device__ __forceinline__ void octet_pass(const LaunchParams& P, float* x, bool valid, uint32_t lid, WorkCounters& wc)
+  {
+    const uint32_t k = lid & 7u;
+    RayState r;
+    r.ox = x[0]; r.oy = x[1]; r.oz = x[2]; r.tnear = x[3];
+    r.dx = x[4]; r.dy = x[5]; r.dz = x[6]; r.tfar = x[7];
+    const uint32_t idx = __float_as_uint(x[8]) & 0x7FFFFFFFu;
+    const float* gp = (const float*)(P.accel.blobs + (size_t)idx * sizeof(GridCell));
+    // Gather3x3 lane -> vertex indices (grid_soa.h:218-223), one nibble per triangle
+    const uint32_t i0 = (0x74634130u >> (4u * k)) & 15u, i1 = (0x55442211u >> (4u * k)) & 15u, i2 = (0x87765443u >> (4u * k)) & 15u;
+    const RelV a = RelV{gp[i0] - r.ox, gp[9u + i0] - r.oy, gp[18u + i0] - r.oz};
+    const RelV b = RelV{gp[i1] - r.ox, gp[9u + i1] - r.oy, gp[18u + i1] - r.oz};
+    const RelV c = RelV{gp[i2] - r.ox, gp[9u + i2] - r.oy, gp[18u + i2] - r.oz};
+    TriHit h;
+    h.t = RT_INF;
+    const bool ok = pluecker_rel(r, a, b, c, r.tfar, h) && valid;
+    const uint32_t mask8 = (uint32_t)(__ballot(ok) >> (lid & 56u)) & 0xffu;
+    if (COUNT && valid && k == 0u) {
+      wc.prims++;
+      wc.inner += (OCCLUDED && mask8) ? (unsigned long long)__ffs(mask8) : 8ull; // the lane-per-ray any-hit loop stops at the first valid triangle
+    }
+    if (OCCLUDED) {
+      if (valid && k == 0u && mask8 != 0u) x[9] = __uint_as_float(1u);
+      return;
+    }
+    float tmin = ok ? h.t : RT_INF;
+    tmin = fminf(tmin, __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(tmin))));
+    tmin = fminf(tmin, __uint_as_float(dpp_u32<DPP_XOR2>(__float_as_uint(tmin))));
+    tmin = fminf(tmin, __uint_as_float(dpp_u32<DPP_HALF_MIRROR>(__float_as_uint(tmin))));
+    const uint32_t win8 = (uint32_t)(__ballot(ok && h.t == tmin) >> (lid & 56u)) & 0xffu;
+    if (ok && win8 != 0u && k == (uint32_t)__ffs(win8) - 1u) {
+      // MapUV (grid_soa.h:148-155): uv = u*uv1 + v*uv2 + (1-u-v)*uv0 on the 16-bit decoded vertex uvs
+      const uint32_t w0 = __float_as_uint(gp[27u + i0]), w1 = __float_as_uint(gp[27u + i1]), w2 = __float_as_uint(gp[27u + i2]);
+      const float s = 8.0f / 0x10000;
+      const float u0 = (float)(w0 & 0xffffu) * s, v0 = (float)(w0 >> 16) * s;
+      const float u1 = (float)(w1 & 0xffffu) * s, v1 = (float)(w1 >> 16) * s;
+      const float u2 = (float)(w2 & 0xffffu) * s, v2 = (float)(w2 >> 16) * s;
+      const float bu = h.u, bv = h.v;
+      const float bw = (1.0f - bu) - bv;
+      x[0] = h.t; x[1] = h.ngx; x[2] = h.ngy; x[3] = h.ngz;
+      x[4] = (bu * u1 + bv * u2) + bw * u0;
+      x[5] = (bu * v1 + bv * v2) + bw * v0;
+      x[6] = gp[36];
+      x[7] = gp[37];
+      x[9] = __uint_as_float(1u);
+    }
+  }
 
   template <bool OCCLUDED, bool COUNT>
   static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t)
@@ -441,6 +496,7 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
 
 template <int MODE, int LEVELS> struct CbvhLeaf
 {
+  static constexpr bool OCTET = false;
   static __device__ __forceinline__ void prepare() { cbvh_tables_init(); }
 
   template <bool OCCLUDED, bool COUNT>

@@ -16,7 +16,70 @@ namespace dev {
 
 template <bool PLUECKER> struct TriLeaf
 {
+  static constexpr bool OCTET = true;
+  // the filter re-trace (exclusion lists) stays on the lane-per-ray path
+  static __device__ __forceinline__ bool octet_ok(const LaunchParams& P) { return P.exclOffsets == nullptr; }
   static __device__ __forceinline__ void prepare() {}
+
+  // Child-parallel form (trace_loop.hip.h): the 8 lanes of an octet test 8 consecutive records of the leaf of the ray in
+  // exchange row `x`, i.e. two of the reference's blocks of 4 per pass: lanes 0-3 block A, lanes 4-7 block B.  Block
+  // semantics are kept exactly: A is tested against the tfar at its entry, its minimum-t lane (lowest lane on ties) wins;
+  // B's depth test `Ts <= absDen * tfar` is then evaluated with the tfar A left behind (so an equal-t hit of the later
+  // block replaces the earlier one, triangle_intersector_pluecker.h:117), its winner chosen the same way.  The winning
+  // lane writes the hit into the row (words 0..7 = t, Ng, u, v, geomID, primID; word 9 = 1).
+  template <bool OCCLUDED, bool COUNT>
+  static __device__ __forceinline__ void octet_pass(const LaunchParams& P, float* x, bool valid, uint32_t lid, WorkCounters& wc)
+  {
+    const TriRecord* __restrict__ prims = P.accel.prims;
+    const uint32_t k = lid & 7u, sh = lid & 56u;
+    RayState r;
+    r.ox = x[0]; r.oy = x[1]; r.oz = x[2]; r.tnear = x[3];
+    r.dx = x[4]; r.dy = x[5]; r.dz = x[6]; r.tfar = x[7];
+    const uint32_t ref = __float_as_uint(x[8]);
+    const uint32_t first = ref & ((1u << TRI_START_BITS) - 1u);
+    uint32_t cnt = valid ? (ref >> TRI_START_BITS) & 31u : 0u;
+    float tfar = r.tfar;
+    for (uint32_t b = 0; __ballot(b < cnt) != 0ull; b += 8u) {
+      const bool present = b + k < cnt;
+      const float4* tp = (const float4*)(prims + first + (present ? b + k : 0u));
+      const float4 A = tp[0], B = tp[1], C = tp[2];
+      if (COUNT && present) wc.prims++;
+      TriHit h;
+      h.t = RT_INF; h.Ts = 0.f; h.absDen = 0.f;
+      const bool ok = (PLUECKER ? pluecker(r, A, B, C, tfar, h) : moeller(r, A, B, C, tfar, h)) && present;
+      const uint32_t m8 = (uint32_t)(__ballot(ok) >> sh) & 0xffu;
+      if (OCCLUDED) { // Occluded1EpilogM: any valid lane
+        if (m8 != 0u) {
+          if (k == 0u) x[9] = __uint_as_float(1u);
+          cnt = 0u;
+        }
+        continue;
+      }
+      // block A (also evaluated, unused, in the lanes of block B: the quads reduce separately)
+      float tq = ok ? h.t : RT_INF;
+      tq = fminf(tq, __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(tq))));
+      tq = fminf(tq, __uint_as_float(dpp_u32<DPP_XOR2>(__float_as_uint(tq))));
+      const float tqm = __uint_as_float(dpp_u32<DPP_HALF_MIRROR>(__float_as_uint(tq)));
+      const float tA = k < 4u ? tq : tqm; // minimum of block A, in all 8 lanes
+      const bool hasA = (m8 & 0x0fu) != 0u;
+      const float tfarB = hasA ? tA : tfar;
+      const bool okB = ok && k >= 4u && (h.Ts <= h.absDen * tfarB);
+      float tb = okB ? h.t : RT_INF;
+      tb = fminf(tb, __uint_as_float(dpp_u32<DPP_XOR1>(__float_as_uint(tb))));
+      tb = fminf(tb, __uint_as_float(dpp_u32<DPP_XOR2>(__float_as_uint(tb))));
+      const float tbm = __uint_as_float(dpp_u32<DPP_HALF_MIRROR>(__float_as_uint(tb)));
+      const float tB = k >= 4u ? tb : tbm; // minimum of block B, in all 8 lanes
+      const uint32_t wA = (uint32_t)(__ballot(ok && k < 4u && h.t == tA) >> sh) & 0x0fu;
+      const uint32_t wB = (uint32_t)(__ballot(okB && h.t == tB) >> sh) & 0xf0u;
+      const uint32_t winner = wB != 0u ? (uint32_t)__ffs(wB) - 1u : (wA != 0u ? (uint32_t)__ffs(wA) - 1u : 8u);
+      if (k == winner) { // Intersect1EpilogM, intersector_epilog.h:293-305
+        x[0] = h.t; x[1] = h.ngx; x[2] = h.ngy; x[3] = h.ngz; x[4] = h.u; x[5] = h.v;
+        x[6] = A.w; x[7] = B.w;
+        x[9] = __uint_as_float(1u);
+      }
+      tfar = wB != 0u ? tB : (wA != 0u ? tA : tfar);
+    }
+  }
 
   template <bool OCCLUDED, bool COUNT>
   static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t rayIdx)

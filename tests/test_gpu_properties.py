@@ -87,40 +87,63 @@ def test_full_size_properties(rtc, bomberman, kind):
     dev.release()
 
 
-@pytest.mark.parametrize("kind", ["tri", "bvh4.compressed.leaf", "default"])
+@pytest.mark.parametrize("kind", ["tri", "tri.moeller", "bvh4.compressed.leaf", "default"])
 def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
-    """The child-parallel (octet) node step (trace_loop.hip.h), taken when few lanes of a wave have node work, against the
-    lane-per-ray node step, and the instrumented kernel twin against the plain one: identical ray records, byte for byte,
-    over repeated runs (the ray-to-wave assignment is dynamic, so every run mixes the lanes differently).  The twin's hit
-    counter must equal the number of hit records."""
+    """The child-parallel (octet) node and leaf steps (trace_loop.hip.h: 8 lanes per ray, taken when few lanes of a wave
+    have node work / from a few rays waiting at a triangle or grid-cell leaf on) against the lane-per-ray steps, and the
+    instrumented kernel twin against the plain one: identical ray records, byte for byte, closest hit and any hit, over
+    repeated runs (the ray-to-wave assignment is dynamic, so every run mixes the lanes differently).  The twin's hit counter
+    must equal the number of hit records."""
     import torch
 
     rg = importlib.import_module("embree-compressed_amd.raygen")
     verts = bomberman[0]
     n = 1_000_000
     rays = torch.from_numpy(rg.make_random_rays(n, verts.min(0), verts.max(0), seed=7)).cuda()
+
+    def scene():
+        if kind == "tri.moeller":
+            dev = rtc.Device("tri_accel=bvh8.triangle4")
+            sc = rtc.Scene(dev)
+            sc.add_triangles(verts, rtc.fan_triangulate(bomberman[1], bomberman[2]))
+            sc.commit()
+        else:
+            dev, sc = _scene(rtc, bomberman, kind)
+        dev.set_stream(torch.cuda.current_stream().cuda_stream)  # clones (torch's stream) and traces are then stream-ordered
+        return dev, sc
+
     monkeypatch.setenv("RTAMD_KERNEL", "lane")
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
-    dev0, sc0 = _scene(rtc, bomberman, kind)
-    dev0.set_stream(torch.cuda.current_stream().cuda_stream)  # clones (torch's stream) and traces are then stream-ordered
+    monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
+    dev0, sc0 = scene()
     ref = rays.clone()
     sc0.intersect1M(ref)
+    occ_ref = rays[:, :48].contiguous().clone()
+    sc0.occluded1M(occ_ref)
     dev0.synchronize()
     hits = int((ref.view(torch.int32)[:, 18] != -1).sum().item())
-    for octmax in ("0", "8", "16", "32"):
+    for octmax, octleaf in (("0", "0"), ("8", "1"), ("16", "8"), ("32", "32"), ("16", None)):
         monkeypatch.setenv("RTAMD_OCT_MAX", octmax)
-        dev, sc = _scene(rtc, bomberman, kind)
-        dev.set_stream(torch.cuda.current_stream().cuda_stream)
+        if octleaf is None:
+            monkeypatch.delenv("RTAMD_OCT_LEAF")  # the library's own default
+        else:
+            monkeypatch.setenv("RTAMD_OCT_LEAF", octleaf)
+        dev, sc = scene()
+        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}"
         for rep in range(2):
             got = rays.clone()
             sc.intersect1M(got)
             dev.synchronize()
-            assert torch.equal(got, ref), f"{kind}: octet threshold {octmax}, plain kernel, run {rep}"
+            assert torch.equal(got, ref), f"{what}, plain kernel, run {rep}"
             got = rays.clone()
             cnt = sc.intersect1M_counted(got)
             dev.synchronize()
-            assert torch.equal(got, ref), f"{kind}: octet threshold {octmax}, counted twin, run {rep}"
+            assert torch.equal(got, ref), f"{what}, counted twin, run {rep}"
             assert cnt["hits"] == hits
+            occ = rays[:, :48].contiguous().clone()
+            sc.occluded1M(occ)
+            dev.synchronize()
+            assert torch.equal(occ, occ_ref), f"{what}, any hit, run {rep}"
         sc.release()
         dev.release()
     sc0.release()
