@@ -63,6 +63,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : 2u) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;
+  p.octSteps = dev->tuneOctSteps;
   p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : ((A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER) ? 16u : 24u);
   p.queues = (uint32_t*)ctx.queues;
   p.exclOffsets = exclOffsets;

@@ -24,6 +24,7 @@ struct LaunchParams
   uint32_t leafBatch;      // lanes waiting at a leaf before the leaf phase runs (tuning knob, env RTAMD_LEAF_BATCH)
   uint32_t blocksPerCU;    // 0 = occupancy-derived (tuning knob, env RTAMD_BLOCKS_PER_CU)
   uint32_t refillBatch;    // idle lanes needed before a wave fetches new rays (tuning knob, env RTAMD_REFILL_BATCH)
+  uint32_t octSteps;       // node steps an octet stays with its ray while the queues still have rays (env RTAMD_OCT_STEPS; unlimited in the drain)
   uint32_t octLeaf;        // waiting rays from which the child-parallel leaf step runs (0 = never; env RTAMD_OCT_LEAF)
   uint32_t octMax;         // lanes with node work up to which a wave runs the child-parallel node step (0 = never; env RTAMD_OCT_MAX)
   uint32_t* queues;        // TRACE_QUEUES work-queue heads, zeroed on the stream before the launch

@@ -62,7 +62,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) // number of set bi
 #define TRACE_OCT_MAX 32
 #endif
 static constexpr int OCT_ROWS = TRACE_OCT_MAX > 0 ? TRACE_OCT_MAX : 1; // rays per wave the exchange area holds
-static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner thread + direction signs
+static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner thread + ray.tfar
 #ifndef TRACE_OCT_PIPE
 #define TRACE_OCT_PIPE 1
 #endif
@@ -231,67 +231,60 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         asm volatile("" : "+v"(lid));
         const uint32_t myRow = lane_rank(nodeMask);
         if (atNode) {
-          if (COUNT) wc.nodes++;
           float* x = octX[myRow];
           tr.store(x, 1);
           x[7] = travFar;
           x[8] = __uint_as_float(cur);
           x[9] = __uint_as_float(sp);
           x[10] = __uint_as_float(tid);
-          x[11] = __uint_as_float((tr.negx() ? 1u : 0u) | (tr.negy() ? 2u : 0u) | (tr.negz() ? 4u : 0u));
+          x[11] = r.tfar;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t k = lid & 7u;
-        // Passes of 8 rays, OCT_PIPE passes at a time: first the node data of all of them is requested (one memory round
-        // trip for the group instead of one per pass), then each pass is evaluated.  Rows past the last ray repeat the
-        // last ray's loads and are masked out of the result.
-        for (uint32_t base0 = 0; base0 < nNode; base0 += 8u * OCT_PIPE) {
-          uint4 n0A[OCT_PIPE];
-          uint32_t crefA[OCT_PIPE], qnA[OCT_PIPE][3], qfA[OCT_PIPE][3];
-#pragma unroll
-          for (int pp = 0; pp < OCT_PIPE; pp++) {
-            if (base0 + 8u * pp < nNode) { // wave-uniform
-              const uint32_t rowc = min(base0 + 8u * pp + (lid >> 3), nNode - 1u);
-              const float* x = octX[rowc];
-              const uint32_t oCur = __float_as_uint(x[8]);
-              const uint32_t sg = __float_as_uint(x[11]); // bit a: direction component a is negative
+        // Passes of 8 rays.  An octet stays with its ray for up to `maxSteps` node steps (descend into the nearest hit
+        // child, push the others, pop when nothing is hit - the loop below IS the traversal loop of
+        // bvh_intersector1.cpp:60-105 for that ray) and hands it back to the owning lane when the ray reaches a leaf, is
+        // finished, or could overflow the LDS part of its stack: in the drain a deep ray then pays one memory round trip
+        // and ~130 instructions per node instead of a full iteration of the wave's loop with three LDS exchanges.  While
+        // the queues still have rays the octets return after P.octSteps steps so that idle lanes are refilled in time.
+        const uint32_t maxSteps = exhausted ? 0xFFFFu : P.octSteps;
+        for (uint32_t base = 0; base < nNode; base += 8u) {
+          const uint32_t row = base + (lid >> 3);
+          const uint32_t rowc = min(row, nNode - 1u);
+          const float* x = octX[rowc];
+          TravRay<ROBUST> t;
+          t.load(x, 1);
+          const float oFar = x[7];
+          uint32_t oCur = __float_as_uint(x[8]);
+          uint32_t oSp = __float_as_uint(x[9]);
+          const uint32_t oTid = __float_as_uint(x[10]);
+          const float rTfar = x[11]; // ray.tfar, for the distance cull of popped entries
+          const bool ngx = t.negx(), ngy = t.negy(), ngz = t.negz();
+          bool done = !(row < nNode); // uniform within an octet
+          uint32_t steps = 0;
+          while (__ballot(!done) != 0ull) {
+            if (!done) {
+              if (COUNT && k == 0u) wc.nodes++;
               const unsigned char* nb = (const unsigned char*)(nodes + oCur);
-              n0A[pp] = *(const uint4*)nb;
-              crefA[pp] = ((const uint32_t*)nb)[4u + k];
+              const uint4 n0 = *(const uint4*)nb;
+              const uint32_t cref = ((const uint32_t*)nb)[4u + k];
               // plane bytes: lower[0..7] at 48/64/80, upper[0..7] eight bytes further (x / y / z)
-#pragma unroll
-              for (int a = 0; a < 3; a++) {
-                const uint32_t neg = (sg >> a) & 1u;
-                qnA[pp][a] = nb[48u + 16u * a + 8u * neg + k];
-                qfA[pp][a] = nb[56u + 16u * a - 8u * neg + k];
-              }
-            }
-          }
-#pragma unroll
-          for (int pp = 0; pp < OCT_PIPE; pp++) {
-            if (base0 + 8u * pp < nNode) {
-              const uint32_t row = base0 + 8u * pp + (lid >> 3);
-              const bool valid = row < nNode;
-              const uint32_t rowc = min(row, nNode - 1u);
-              const float* x = octX[rowc];
-              TravRay<ROBUST> t;
-              t.load(x, 1);
-              const float oFar = x[7];
-              const uint32_t oSp = __float_as_uint(x[9]);
-              const uint32_t oTid = __float_as_uint(x[10]);
-              const uint4 n0 = n0A[pp];
-              const uint32_t cref = crefA[pp];
+              const uint32_t qnx = nb[48u + (ngx ? 8u : 0u) + k], qfx = nb[48u + (ngx ? 0u : 8u) + k];
+              const uint32_t qny = nb[64u + (ngy ? 8u : 0u) + k], qfy = nb[64u + (ngy ? 0u : 8u) + k];
+              const uint32_t qnz = nb[80u + (ngz ? 8u : 0u) + k], qfz = nb[80u + (ngz ? 0u : 8u) + k];
               const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
               const float sx = __uint_as_float((n0.w & 0xffu) << 23);
               const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
               const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
-              const float npx = madd((float)qnA[pp][0], sx, ox), npy = madd((float)qnA[pp][1], sy, oy), npz = madd((float)qnA[pp][2], sz, oz);
-              const float fpx = madd((float)qfA[pp][0], sx, ox), fpy = madd((float)qfA[pp][1], sy, oy), fpz = madd((float)qfA[pp][2], sz, oz);
+              const float npx = madd((float)qnx, sx, ox), npy = madd((float)qny, sy, oy), npz = madd((float)qnz, sz, oz);
+              const float fpx = madd((float)qfx, sx, ox), fpy = madd((float)qfy, sy, oy), fpz = madd((float)qfz, sz, oz);
               const float tN = fmaxf(t.nearT(npx, npy, npz), t.tnear);
               const float tF = fminf(t.farT(fpx, fpy, fpz), oFar);
-              const bool h = valid & (tN <= tF) & (cref != REF_EMPTY);
+              const bool h = (tN <= tF) & (cref != REF_EMPTY);
               const uint32_t dist = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+              // all 8 lanes of an octet are in here together (`done` is uniform within the octet), so the ballot bits and
+              // the DPP partners of a lane are always live
               const uint32_t mask8 = (uint32_t)(__ballot(h) >> (lid & 56u)) & 0xffu;
               const uint32_t nhit = (uint32_t)__popc(mask8);
               uint32_t rank;
@@ -312,16 +305,37 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
                 rank += d6 < dist + ((k ^ 6u) > k ? 1u : 0u) ? 1u : 0u;
                 rank += m < dist + ((k ^ 7u) > k ? 1u : 0u) ? 1u : 0u;
               }
-              if (valid) {
-                const uint32_t top = oSp + nhit - 1u; // nhit == 0: unused
-                if (h) {
-                  if (rank == 0u) {
-                    octX[row][8] = __uint_as_float(cref);
-                    octX[row][9] = __uint_as_float(top);
-                  } else ldsStack[top - rank][oTid] = make_uint2(cref, dist);
-                } else if (nhit == 0u && k == 0u) octX[row][8] = __uint_as_float(REF_EMPTY);
+              if (nhit != 0u) {
+                const uint32_t top = oSp + nhit - 1u;
+                if (h && rank != 0u) ldsStack[top - rank][oTid] = make_uint2(cref, dist);
+                // the nearest child's reference, to all lanes of the octet (exactly one lane contributes; a child
+                // reference is never 0: node 0 is the root)
+                uint32_t v = (h && rank == 0u) ? cref : 0u;
+                v |= dpp_u32<DPP_XOR1>(v);
+                v |= dpp_u32<DPP_XOR2>(v);
+                v |= dpp_u32<DPP_HALF_MIRROR>(v);
+                oCur = v;
+                oSp = top;
+              } else {
+                // pop (bvh_intersector1.cpp:80-88): all lanes of the octet read the same entries
+                for (;;) {
+                  if (oSp == 0u) { oCur = REF_EMPTY; done = true; break; } // stack empty: the ray is finished
+                  oSp--;
+                  const uint2 e = ldsStack[oSp][oTid];
+                  if (e.x == REF_EMPTY) continue;
+                  if (!OCCLUDED && __uint_as_float(e.y) > rTfar) continue;
+                  oCur = e.x;
+                  break;
+                }
               }
+              steps++;
+              // back to the owning lane: at a leaf, after maxSteps steps, or when the next push could leave the LDS stack
+              if ((oCur & REF_LEAF) || steps >= maxSteps || oSp + 7u > (uint32_t)TRACE_LDS_STACK) done = true;
             }
+          }
+          if (row < nNode && k == 0u) {
+            octX[row][8] = __uint_as_float(oCur);
+            octX[row][9] = __uint_as_float(oSp);
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
