@@ -564,7 +564,11 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__global__ __launch_bounds__(TRACE_BLOCK, TRACE_MIN_WAVES_PER_SIMD) void trace_kernel(LaunchParams P)
+// The instrumented twin carries ~25 more live registers (counters, time stamps): bounded at 3 waves per SIMD it spills 90-150
+// bytes per lane in the subdivision kernels, and builds with that much scratch in the twin returned wrong records for one
+// or two waves per launch (eager path, reproducible per build, the plain kernel never affected; cause not found).  The twin
+// is a diagnostic path, so it simply gets the registers: 2 waves per SIMD, no scratch.
+__global__ __launch_bounds__(TRACE_BLOCK, COUNT ? 2 : Leaf::MIN_WAVES) void trace_kernel(LaunchParams P)
 {
   __shared__ uint2 ldsStack[TRACE_LDS_STACK + 1][TRACE_BLOCK]; // + one scratch row for the branch-free pushes
   __shared__ __attribute__((aligned(16))) float octX[TRACE_BLOCK / 64][OCT_ROWS][OCT_WORDS]; // octet node step: per-wave exchange rows
