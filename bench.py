@@ -51,8 +51,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--rays", type=int, default=1_000_000, help="rays per step per GPU")
     ap.add_argument("--workload", default="cbvh.leaf", choices=list(WORKLOADS))
     ap.add_argument("--levels", default="6,3", help="subdivision level, compression level")
