@@ -60,7 +60,10 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   // A batch alone on the chip is fastest with two workgroups per CU; when two or more batches are running on other
   // streams a leaner grid is better: every wave pays its deepest ray's iterations, so fewer waves per batch waste fewer
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
-  p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : 2u) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
+  // (The grid-cell kernel, whose leaves are always tested 8 lanes per ray, needs 118 VGPRs: four waves per SIMD fit, and a batch
+  // alone on the chip is 10 % faster with four workgroups per CU; 0.169 -> 0.151 ms.)
+  const uint32_t aloneBlocks = A.kind == ACCEL_GRIDSOA ? 4u : 2u;
+  p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;
   p.octSteps = dev->tuneOctSteps;

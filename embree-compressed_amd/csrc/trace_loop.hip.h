@@ -454,13 +454,18 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         // Child-parallel leaf step (leaves whose primitives map onto the 8 lanes of an octet): lane 8g+k tests primitive k
         // of the leaf of the g-th waiting ray.  A pass of 8 rays costs about a fifth of the lane-per-ray leaf code and runs
         // on full wavefronts, so the lanes need not wait for P.leafBatch companions: 8 waiting rays are enough.
-        if (P.octLeaf != 0u && Leaf::octet_ok(P) && nLeaf <= (uint32_t)OCT_ROWS && (nLeaf >= P.octLeaf || !nodeWork)) {
+        // (OCTET_ONLY leaves have no lane-per-ray form in this kernel: at most OCT_ROWS waiting rays go through per phase, the
+        // others wait for the next one; their lane-per-ray code - 40 live registers for a grid cell - is not even compiled in)
+        if ((Leaf::OCTET_ONLY || (P.octLeaf != 0u && Leaf::octet_ok(P) && nLeaf <= (uint32_t)OCT_ROWS)) &&
+            (nLeaf >= (Leaf::OCTET_ONLY ? max(P.octLeaf, 1u) : P.octLeaf) || !nodeWork)) {
           leafDone = true;
           if (COUNT) nLeafPhase++;
           uint32_t lid = laneId;
           asm volatile("" : "+v"(lid)); // see the node step: keeps the lane constants of this block out of the loop's live set
           const uint32_t myRow = lane_rank(leafMask);
-          if (atLeafNow) {
+          const uint32_t nRows = min(nLeaf, (uint32_t)OCT_ROWS);
+          const bool inPhase = atLeafNow && myRow < nRows;
+          if (inPhase) {
             if (COUNT) wc.leaves++;
             float* x = octX[myRow];
             x[0] = r.ox; x[1] = r.oy; x[2] = r.oz; x[3] = r.tnear;
@@ -470,13 +475,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (uint32_t base = 0; base < nLeaf; base += 8u) {
+          for (uint32_t base = 0; base < nRows; base += 8u) {
             const uint32_t row = base + (lid >> 3);
-            Leaf::template octet_pass<OCCLUDED, COUNT>(P, octX[min(row, nLeaf - 1u)], row < nLeaf, lid, wc);
+            Leaf::template octet_pass<OCCLUDED, COUNT>(P, octX[min(row, nRows - 1u)], row < nRows, lid, wc);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (atLeafNow) {
+          if (inPhase) {
             const float* x = octX[myRow];
             if (__float_as_uint(x[9]) != 0u) {
               r.hit = 1u;
@@ -493,9 +498,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           }
         }
       }
-      if (!leafDone && (nLeaf >= P.leafBatch || !nodeWork)) {
+      if (!Leaf::OCTET_ONLY && !leafDone && (nLeaf >= P.leafBatch || !nodeWork)) {
         if (COUNT) nLeafPhase++;
-        if (atLeafNow) {
+        if constexpr (!Leaf::OCTET_ONLY) if (atLeafNow) {
           if (COUNT) wc.leaves++;
           if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc, rayIdx)) {
             r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201

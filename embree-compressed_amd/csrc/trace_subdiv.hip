@@ -71,6 +71,7 @@ __device__ __forceinline__ bool pluecker_rel(const RayState& r, const RelV a, co
 struct GridCellLeaf
 {
   static constexpr bool OCTET = true;
+  static constexpr bool OCTET_ONLY = true; // lane kernel: cells are always tested 8 lanes per ray (intersect() below serves the ray-pool kernel)
   static constexpr int MIN_WAVES = TRACE_MIN_WAVES_PER_SIMD;
   static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
   static __device__ __forceinline__ void prepare() {}
@@ -498,6 +499,7 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
 template <int MODE, int LEVELS> struct CbvhLeaf
 {
   static constexpr bool OCTET = false;
+  static constexpr bool OCTET_ONLY = false;
   // four and five quadtree levels keep four / five parent boxes in registers: bounded at 3 waves per SIMD those kernels spill
   // 60-330 bytes per lane, so they are compiled for 2 waves per SIMD (<= 256 VGPRs) instead
   static constexpr int MIN_WAVES = LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD;

@@ -17,6 +17,7 @@ namespace dev {
 template <bool PLUECKER> struct TriLeaf
 {
   static constexpr bool OCTET = true;
+  static constexpr bool OCTET_ONLY = false; // the filter re-trace needs the lane-per-ray form
   static constexpr int MIN_WAVES = TRACE_MIN_WAVES_PER_SIMD;
   // the filter re-trace (exclusion lists) stays on the lane-per-ray path
   static __device__ __forceinline__ bool octet_ok(const LaunchParams& P) { return P.exclOffsets == nullptr; }

@@ -112,10 +112,13 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
         dev.set_stream(torch.cuda.current_stream().cuda_stream)  # clones (torch's stream) and traces are then stream-ordered
         return dev, sc
 
-    monkeypatch.setenv("RTAMD_KERNEL", "lane")
+    # reference = lane-per-ray steps only.  Grid cells have no lane-per-ray leaf code in the lane kernel any more (they are
+    # always tested 8 lanes per ray): their reference comes from the ray-pool kernel, which runs GridCellLeaf::intersect
+    monkeypatch.setenv("RTAMD_KERNEL", "pool" if kind == "default" else "lane")
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
     monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
     dev0, sc0 = scene()
+    monkeypatch.setenv("RTAMD_KERNEL", "lane")
     ref = rays.clone()
     sc0.intersect1M(ref)
     occ_ref = rays[:, :48].contiguous().clone()
