@@ -53,6 +53,7 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_REFILL_BATCH")) tuneRefillBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_LEAF")) tuneOctLeaf = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_STEPS")) tuneOctSteps = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_ALONE_BLOCKS")) tuneAloneBlocksOct = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_MAX")) tuneOctMax = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_KERNEL")) tunePoolKernel = strcmp(env, "pool") == 0 ? 1u : (strcmp(env, "lane") == 0 ? 0u : 2u);
   if (const char* env = getenv("RTAMD_BLOCKS_PER_CU")) { tuneBlocksPerCU = (uint32_t)std::max(0, atoi(env)); tuneBlocksAuto = false; }

@@ -62,7 +62,7 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
   // (The grid-cell kernel, whose leaves are always tested 8 lanes per ray, needs 118 VGPRs: four waves per SIMD fit, and a batch
   // alone on the chip is 10 % faster with four workgroups per CU; 0.169 -> 0.151 ms.)
-  const uint32_t aloneBlocks = A.kind == ACCEL_GRIDSOA ? 4u : 2u;
+  const uint32_t aloneBlocks = A.kind == ACCEL_GRIDSOA ? dev->tuneAloneBlocksOct : 2u;
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? 1u : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;

@@ -472,6 +472,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
             x[4] = r.dx; x[5] = r.dy; x[6] = r.dz; x[7] = r.tfar;
             x[8] = __uint_as_float(cur);
             x[9] = __uint_as_float(0u); // result flag
+            x[10] = __uint_as_float(rayIdx);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();

@@ -17,10 +17,13 @@ namespace dev {
 template <bool PLUECKER> struct TriLeaf
 {
   static constexpr bool OCTET = true;
-  static constexpr bool OCTET_ONLY = false; // the filter re-trace needs the lane-per-ray form
+  // Both forms stay in the lane kernel.  Measured with the lane-per-ray form dropped (127 VGPRs, four waves per SIMD): random
+  // rays 18.0 -> 19.2 Grays/s in flight, 0.098 -> 0.089 ms alone, but rays that visit many full leaves lose: camera rays 11.4 ->
+  // 10.8, bounce rays 10.3 -> 9.4, shadow rays 15.9 -> 13.2 Grays/s (8 lanes per ray test a 4-triangle leaf at half occupancy;
+  // with 64 rays at a leaf the lane-per-ray block loop is the better use of the wave).
+  static constexpr bool OCTET_ONLY = false;
   static constexpr int MIN_WAVES = TRACE_MIN_WAVES_PER_SIMD;
-  // the filter re-trace (exclusion lists) stays on the lane-per-ray path
-  static __device__ __forceinline__ bool octet_ok(const LaunchParams& P) { return P.exclOffsets == nullptr; }
+  static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
   static __device__ __forceinline__ void prepare() {}
 
   // Child-parallel form (trace_loop.hip.h): the 8 lanes of an octet test 8 consecutive records of the leaf of the ray in
@@ -48,7 +51,15 @@ template <bool PLUECKER> struct TriLeaf
       if (COUNT && present) wc.prims++;
       TriHit h;
       h.t = RT_INF; h.Ts = 0.f; h.absDen = 0.f;
-      const bool ok = (PLUECKER ? pluecker(r, A, B, C, tfar, h) : moeller(r, A, B, C, tfar, h)) && present;
+      bool ok = (PLUECKER ? pluecker(r, A, B, C, tfar, h) : moeller(r, A, B, C, tfar, h)) && present;
+      if (ok && P.exclOffsets) { // filter re-trace: a candidate the host filter rejected before stays rejected
+        const uint32_t rayIdx = __float_as_uint(x[10]);
+        const uint32_t e1 = P.exclOffsets[rayIdx + 1];
+        for (uint32_t e = P.exclOffsets[rayIdx]; e < e1; e++) {
+          const uint2 q = P.exclPairs[e];
+          if (q.x == __float_as_uint(A.w) && q.y == __float_as_uint(B.w)) ok = false;
+        }
+      }
       const uint32_t m8 = (uint32_t)(__ballot(ok) >> sh) & 0xffu;
       if (OCCLUDED) { // Occluded1EpilogM: any valid lane
         if (m8 != 0u) {

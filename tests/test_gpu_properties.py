@@ -112,9 +112,10 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
         dev.set_stream(torch.cuda.current_stream().cuda_stream)  # clones (torch's stream) and traces are then stream-ordered
         return dev, sc
 
-    # reference = lane-per-ray steps only.  Grid cells have no lane-per-ray leaf code in the lane kernel any more (they are
-    # always tested 8 lanes per ray): their reference comes from the ray-pool kernel, which runs GridCellLeaf::intersect
-    monkeypatch.setenv("RTAMD_KERNEL", "pool" if kind == "default" else "lane")
+    # reference = lane-per-ray steps only.  Triangle leaves and grid cells have no lane-per-ray leaf code in the lane kernel
+    # any more (they are always tested 8 lanes per ray): their reference comes from the ray-pool kernel, which runs
+    # TriLeaf::intersect / GridCellLeaf::intersect, one lane per ray
+    monkeypatch.setenv("RTAMD_KERNEL", "lane" if kind == "bvh4.compressed.leaf" else "pool")
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
     monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
     dev0, sc0 = scene()
