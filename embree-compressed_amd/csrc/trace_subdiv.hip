@@ -235,23 +235,27 @@ __device__ __forceinline__ uint32_t compact1by1(uint32_t x)
   return x;
 }
 
+// Kept small on purpose (the blob walk is what holds this kernel at the register limit): node / cell / grid addresses are
+// constant offsets from the header (the level count is a template parameter), rdir_far, the local origin, rcp_edges and extent
+// are re-derived or re-read from the (L1-hot) header where they are used.
 struct CbvhCtx
 {
   const CbvhHeader* H;
-  const uint32_t* nodes;
-  const uint8_t* leaves;
-  const float* grid;
   RayState* r;
-  uint32_t elems;
   // projected ray (compressed.h:470-508) and its robust TravRay<4,4,true> constants (:522-523)
   float ox, oy, oz, dx, dy, dz;
-  float rnx, rny, rnz, rfx, rfy, rfz;
+  float rnx, rny, rnz; // rdir_near; rdir_far = rdir_near * (1+3ulp) is formed per node
   float travFar; // travRay.tfar: fixed for the whole blob
   float tfar;    // local tfar, shrinks with hits
   float near, zFactor;
   uint32_t special; // 0/1 in a vector register (see RayState::hit)
-  float lox, loy, loz; // lOrg
-  float rcp_edges, extent;
+};
+template <int LEVELS> struct CbvhGeom
+{
+  static constexpr uint32_t ELEMS = ((1u << (2 * LEVELS)) - 1u) / 3u; // inner nodes of the complete quadtree
+  static __device__ __forceinline__ const uint32_t* nodes(const CbvhHeader* H) { return (const uint32_t*)((const uint8_t*)H + CBVH_HEADER_BYTES); }
+  static __device__ __forceinline__ const uint8_t* leaves(const CbvhHeader* H) { return (const uint8_t*)H + CBVH_HEADER_BYTES + 4u * ELEMS; }
+  static __device__ __forceinline__ const float* grid(const CbvhHeader* H) { return (const float*)((const uint8_t*)H + CBVH_HEADER_BYTES + 4u * ELEMS); }
 };
 
 __device__ __forceinline__ void project3(const float* m, float x, float y, float z, float& ox, float& oy, float& oz)
@@ -288,7 +292,11 @@ __device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float 
     // flat frame: un-project the local hit point and measure the distance in the rotated world frame (:583-587)
     float px, py, pz;
     project3(H->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
-    const float ex = px - c.lox, ey = py - c.loy, ez = pz - c.loz;
+    const float* S = H->space; // lOrg again (same fma chain as at blob entry)
+    const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
+    const float loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
+    const float loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
+    const float ex = px - lox, ey = py - loy, ez = pz - loz;
     r.tfar = sqrtf(madd(ex, ex, madd(ey, ey, ez * ez)));
   } else
     r.tfar = t / c.zFactor + c.near;
@@ -360,27 +368,27 @@ __device__ __forceinline__ bool grid_triangle(const float* v0, const float* v1, 
 }
 
 // `zz` (leaf mode): the cell's two height bytes, z12 in bits 0..7 and z34 in bits 8..15
-template <int MODE, bool COUNT>
+template <int MODE, int LEVELS, bool COUNT>
 __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz, float tN, float tF, float blx, float bly, float blz,
                                           float bhx, float bhy, float bhz, WorkCounters& wc)
 {
   if (MODE == MODE_LEAF) { // compressed.h:539-593
     if (tN >= c.tfar) return;
     const float dimZ = bhz - blz;
-    const float range = (1.f + 2.f * c.extent) * dimZ;
+    const float range = (1.f + 2.f * c.H->extent) * dimZ;
     const float dz = 0.0625f * range; // getDelta() = rcp(16) (compressed_leaf.h:109-111)
     const float rcpF = 0.0625f * range;
-    const float off = blz - dimZ * c.extent;
+    const float off = blz - dimZ * c.H->extent;
     const uint32_t z12 = zz & 0xffu, z34 = (zz >> 8) & 0xffu;
     const float z1 = off + rcpF * (float)(z12 >> 4), z2 = off + rcpF * (float)(z12 & 0xf);
     const float z3 = off + rcpF * (float)(z34 >> 4), z4 = off + rcpF * (float)(z34 & 0xf);
     float u, v, t = c.tfar;
     if (COUNT) wc.inner++;
-    if (intersect_patch(idx, c.rcp_edges, dz, tN, tF, z1, z2, z3, z4, blx, bly, bhx, bhy, c, u, v, t)) cbvh_commit(c, u, v, t);
+    if (intersect_patch(idx, c.H->rcp_edges, dz, tN, tF, z1, z2, z3, z4, blx, bly, bhx, bhy, c, u, v, t)) cbvh_commit(c, u, v, t);
   } else if (MODE == MODE_GRID) { // compressed.h:597-611, compressed_help.h:278-308
     const uint32_t x = compact1by1(idx), y = compact1by1(idx >> 1);
     const uint32_t w = c.H->grid_width;
-    const float* g0 = c.grid + 3 * (y * w + x);
+    const float* g0 = CbvhGeom<LEVELS>::grid(c.H) + 3 * (y * w + x);
     const float* g1 = g0 + 3;
     const float* g2 = g0 + 3 * w;
     const float* g3 = g2 + 3;
@@ -390,8 +398,8 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz,
     const bool hit1 = grid_triangle(q0, q1, q2, r);
     const bool hit2 = grid_triangle(q3, q2, q1, r);
     if (hit1 || hit2) {
-      const float uu = hit2 ? ((float)x + (1.f - r.u)) * c.rcp_edges : ((float)x + r.u) * c.rcp_edges;
-      const float vv = hit2 ? ((float)y + (1.f - r.v)) * c.rcp_edges : ((float)y + r.v) * c.rcp_edges;
+      const float uu = hit2 ? ((float)x + (1.f - r.u)) * c.H->rcp_edges : ((float)x + r.u) * c.H->rcp_edges;
+      const float vv = hit2 ? ((float)y + (1.f - r.v)) * c.H->rcp_edges : ((float)y + r.v) * c.H->rcp_edges;
       r.ngx = 1.f; r.ngy = 0.f; r.ngz = 0.f;
       r.u = c.H->uv0x + uu * c.H->uv1x;
       r.v = c.H->uv0y + vv * c.H->uv1y;
@@ -403,8 +411,8 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz,
   } else { // voxel, compressed.h:614-654
     const float is = tN;
     if (is <= c.tfar) {
-      const float u = (((c.ox + c.dx * is) - blx) / (bhx - blx) + (float)compact1by1(idx)) * c.rcp_edges;
-      const float v = (((c.oy + c.dy * is) - bly) / (bhy - bly) + (float)compact1by1(idx >> 1)) * c.rcp_edges;
+      const float u = (((c.ox + c.dx * is) - blx) / (bhx - blx) + (float)compact1by1(idx)) * c.H->rcp_edges;
+      const float v = (((c.oy + c.dy * is) - bly) / (bhy - bly) + (float)compact1by1(idx >> 1)) * c.H->rcp_edges;
       if (COUNT) wc.inner++;
       cbvh_commit(c, u, v, is);
     }
@@ -418,16 +426,16 @@ typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 // yz, y).  The four children of node `curr` are the consecutive words 4*curr+1 .. 4*curr+4 (or, below the last inner
 // level, the consecutive 2-byte cells 4*curr+1-elems ..): they are requested with ONE load as soon as the node is
 // entered, so the round trip overlaps the decode and the slab test of this node instead of following them per child.
-template <int MODE, int REM, bool COUNT>
+template <int MODE, int LEVELS, int REM, bool COUNT>
 __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w, float blx, float bly, float blz, float bhx, float bhy,
                                           float bhz, WorkCounters& wc)
 {
   uint32_t cw[4] = {0u, 0u, 0u, 0u};
   if constexpr (REM > 1) {
-    const u32x4_a4 q = *(const u32x4_a4*)(c.nodes + (4u * curr + 1u));
+    const u32x4_a4 q = *(const u32x4_a4*)(CbvhGeom<LEVELS>::nodes(c.H) + (4u * curr + 1u));
     cw[0] = q.x; cw[1] = q.y; cw[2] = q.z; cw[3] = q.w;
   } else if constexpr (MODE == MODE_LEAF) {
-    const u32x2_a4 q = *(const u32x2_a4*)(c.leaves + 2u * (4u * curr + 1u - c.elems)); // 4 cells x 2 bytes
+    const u32x2_a4 q = *(const u32x2_a4*)(CbvhGeom<LEVELS>::leaves(c.H) + 2u * (4u * curr + 1u - CbvhGeom<LEVELS>::ELEMS)); // 4 cells x 2 bytes
     cw[0] = q.x; cw[1] = q.y;
   }
   if (COUNT) wc.inner++;
@@ -447,11 +455,13 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
 
   // intersectNodeRobust (node_intersector1.h:351-368) on the two x columns, two y rows, one z slab
   const bool negx = !(c.rnx >= 0.f), negy = !(c.rny >= 0.f), negz = !(c.rnz >= 0.f);
-  const float nX0 = ((negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((negx ? lx0 : ux0) - c.ox) * c.rfx;
-  const float nX1 = ((negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((negx ? lx1 : ux1) - c.ox) * c.rfx;
-  const float nY0 = ((negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((negy ? ly0 : uy0) - c.oy) * c.rfy;
-  const float nY1 = ((negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((negy ? ly1 : uy1) - c.oy) * c.rfy;
-  const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * c.rfz;
+  const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
+  const float rfx = c.rnx * ulp3, rfy = c.rny * ulp3, rfz = c.rnz * ulp3; // rdir_far (node_intersector1.h:116-118)
+  const float nX0 = ((negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((negx ? lx0 : ux0) - c.ox) * rfx;
+  const float nX1 = ((negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((negx ? lx1 : ux1) - c.ox) * rfx;
+  const float nY0 = ((negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((negy ? ly0 : uy0) - c.oy) * rfy;
+  const float nY1 = ((negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((negy ? ly1 : uy1) - c.oy) * rfy;
+  const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * rfz;
   float tN[4], tF[4];
   uint32_t d[4];
   uint32_t mask = 0;
@@ -490,9 +500,9 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
       float tn = tN[0], tf = tF[0];
 #pragma unroll
       for (int q = 1; q < 4; q++) { tn = rr == q ? tN[q] : tn; tf = rr == q ? tF[q] : tf; }
-      cbvh_cell<MODE, COUNT>(c, child - c.elems, cword, tn, tf, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+      cbvh_cell<MODE, LEVELS, COUNT>(c, child - CbvhGeom<LEVELS>::ELEMS, cword, tn, tf, cbx0, cby0, lz, cbx1, cby1, uz, wc);
     } else
-      cbvh_node<MODE, REM - 1, COUNT>(c, child, cword, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+      cbvh_node<MODE, LEVELS, REM - 1, COUNT>(c, child, cword, cbx0, cby0, lz, cbx1, cby1, uz, wc);
   }
 }
 
@@ -528,19 +538,13 @@ template <int MODE, int LEVELS> struct CbvhLeaf
 
     CbvhCtx c;
     c.H = H;
-    c.nodes = (const uint32_t*)(blob + CBVH_HEADER_BYTES);
-    const uint32_t rootWord = c.nodes[0]; // requested together with the header: no extra round trip after the frustum test
-    c.elems = H->elems;
-    c.leaves = blob + CBVH_HEADER_BYTES + 4u * c.elems;
-    c.grid = (const float*)(blob + CBVH_HEADER_BYTES + 4u * c.elems);
+    const uint32_t rootWord = CbvhGeom<LEVELS>::nodes(H)[0]; // requested together with the header: no extra round trip after the frustum test
     c.r = &r;
-    c.rcp_edges = H->rcp_edges;
-    c.extent = H->extent;
     // rotate the ray into the local frame (:458-459; xfmPoint/xfmVector are fma chains, linearspace3.h:168-169)
     const float* S = H->space;
-    c.lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
-    c.loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
-    c.loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
+    const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
+    const float loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
+    const float loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
     const float ldx = madd(r.dx, S[0], madd(r.dy, S[1], r.dz * S[2]));
     const float ldy = madd(r.dx, S[3], madd(r.dy, S[4], r.dz * S[5]));
     const float ldz = madd(r.dx, S[6], madd(r.dy, S[7], r.dz * S[8]));
@@ -550,12 +554,12 @@ template <int MODE, int LEVELS> struct CbvhLeaf
     {
       const float* B = H->box;
       const float rz = 1.0f / (fabsf(ldz) < 1e-18f ? 1e-18f : ldz); // rcp_safe
-      const float orz = c.loz * rz;
+      const float orz = loz * rz;
       const float t1z = B[0] * rz - orz, t2z = B[1] * rz - orz;
-      const float t1x = intersect_line(B[2], B[3], B[6], B[7], c.lox, c.loy, ldx, ldy);
-      const float t2x = intersect_line(B[4], B[5], B[8], B[9], c.lox, c.loy, ldx, ldy);
-      const float t1y = intersect_line(B[2], B[3], B[4], B[5], c.lox, c.loy, ldx, ldy);
-      const float t2y = intersect_line(B[6], B[7], B[8], B[9], c.lox, c.loy, ldx, ldy);
+      const float t1x = intersect_line(B[2], B[3], B[6], B[7], lox, loy, ldx, ldy);
+      const float t2x = intersect_line(B[4], B[5], B[8], B[9], lox, loy, ldx, ldy);
+      const float t1y = intersect_line(B[2], B[3], B[4], B[5], lox, loy, ldx, ldy);
+      const float t2y = intersect_line(B[6], B[7], B[8], B[9], lox, loy, ldx, ldy);
       const float near1 = fminf(fminf(t1x, t2x), fminf(t1y, t2y));
       const float far1 = fmaxf(fmaxf(t1x, t2x), fmaxf(t1y, t2y));
       near = fmaxf(fmaxf(fminf(t1z, t2z), near1), near);
@@ -566,8 +570,8 @@ template <int MODE, int LEVELS> struct CbvhLeaf
 
     // projected ray between entry and exit point (:470-508)
     float tx, ty, tz;
-    project3(H->proj, c.lox + ldx * near, c.loy + ldy * near, c.loz + ldz * near, c.ox, c.oy, c.oz);
-    project3(H->proj, c.lox + ldx * far, c.loy + ldy * far, c.loz + ldz * far, tx, ty, tz);
+    project3(H->proj, lox + ldx * near, loy + ldy * near, loz + ldz * near, c.ox, c.oy, c.oz);
+    project3(H->proj, lox + ldx * far, loy + ldy * far, loz + ldz * far, tx, ty, tz);
     c.dx = tx - c.ox; c.dy = ty - c.oy; c.dz = tz - c.oz;
     c.special = 0u;
     c.zFactor = 0.f;
@@ -595,10 +599,9 @@ template <int MODE, int LEVELS> struct CbvhLeaf
       const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
       const float zx = fabsf(c.dx) < 1e-18f ? 1e-18f : c.dx, zy = fabsf(c.dy) < 1e-18f ? 1e-18f : c.dy, zz = fabsf(c.dz) < 1e-18f ? 1e-18f : c.dz;
       c.rnx = 1.0f / zx; c.rny = 1.0f / zy; c.rnz = 1.0f / zz;
-      c.rfx = c.rnx * ulp3; c.rfy = c.rny * ulp3; c.rfz = c.rnz * ulp3;
     }
     // root: local frame box xy in [-1,1], z from the leaf data (:517-519)
-    cbvh_node<MODE, LEVELS, COUNT>(c, 0u, rootWord, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);
+    cbvh_node<MODE, LEVELS, LEVELS, COUNT>(c, 0u, rootWord, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);
     return false;
   }
 };
