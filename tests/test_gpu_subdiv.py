@@ -243,3 +243,24 @@ def test_gpu_reproduces_the_subdiv_golden_fixture(rtc, po, bomberman, accel):
         assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(np.abs(b), 1e-3)), f
     sc.release()
     dev.release()
+
+
+@pytest.mark.parametrize("accel", ["bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.grid"])
+@pytest.mark.parametrize("L,Cl", [(4, 1), (5, 4), (6, 5)])
+def test_compression_levels_parity(rtc, po, bomberman, accel, L, Cl):
+    """The cBVH kernels are instantiated per compression level C (node / cell / grid addresses are compile-time offsets from
+    the blob header): the shallowest and the two deepest levels, all three modes, against the oracle's stack-based walk."""
+    verts, fs, fi = bomberman
+    dev, sc = _build(rtc, accel, verts, fs, fi, L, Cl)
+    st = sc.stats()
+    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
+    else:
+        orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
+    want = po.make_random_rays(200_000, verts.min(0), verts.max(0), seed=3, double_eval=True)
+    got = want.copy()
+    orc.intersect1M(want, nthreads=8)
+    sc.intersect1M(got)
+    assert compare_hits(got, want, what=f"{accel} L{L} C{Cl}") > 20_000
+    sc.release()
+    dev.release()
