@@ -37,6 +37,10 @@ namespace dev {
 #endif
 // 1: the instrumented twin also reads the shader clock around every phase (cyclesFetch/Node/Leaf/Pop); the reads
 // serialise the scalar memory pipe and slow that twin down ~2x, so the default build leaves those four counters at 0
+// waves per SIMD the instrumented twins are compiled for (see trace_kernel below)
+#ifndef TRACE_COUNT_MIN_WAVES
+#define TRACE_COUNT_MIN_WAVES(Leaf) 2
+#endif
 #ifndef TRACE_PHASE_STAMPS
 #define TRACE_PHASE_STAMPS 0
 #endif
@@ -239,7 +243,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           x[10] = __uint_as_float(tid);
           x[11] = r.tfar;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t k = lid & 7u;
         // Passes of 8 rays.  An octet stays with its ray for up to `maxSteps` node steps (descend into the nearest hit
@@ -338,7 +342,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
             octX[row][9] = __uint_as_float(oSp);
           }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (atNode) {
           cur = __float_as_uint(octX[myRow][8]);
@@ -474,13 +478,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
             x[9] = __uint_as_float(0u); // result flag
             x[10] = __uint_as_float(rayIdx);
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
           for (uint32_t base = 0; base < nRows; base += 8u) {
             const uint32_t row = base + (lid >> 3);
             Leaf::template octet_pass<OCCLUDED, COUNT>(P, octX[min(row, nRows - 1u)], row < nRows, lid, wc);
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
           if (inPhase) {
             const float* x = octX[myRow];
@@ -570,11 +574,16 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-// The instrumented twin carries ~25 more live registers (counters, time stamps): bounded at 3 waves per SIMD it spills 90-150
-// bytes per lane in the subdivision kernels, and builds with that much scratch in the twin returned wrong records for one
-// or two waves per launch (eager path, reproducible per build, the plain kernel never affected; cause not found).  The twin
-// is a diagnostic path, so it simply gets the registers: 2 waves per SIMD, no scratch.
-__global__ __launch_bounds__(TRACE_BLOCK, COUNT ? 2 : Leaf::MIN_WAVES) void trace_kernel(LaunchParams P)
+// The instrumented twin carries ~25 more live registers (counters, time stamps).  It is compiled for 2 waves per SIMD (<= 256
+// VGPRs, no scratch) because that is the occupancy a batch alone on the chip runs at anyway (two workgroups per CU), so the
+// twin's timeline stays close to the plain kernel's; bounded at 3 waves it spills 76-180 bytes per lane.
+// Correctness does not depend on this: round 1 blamed wrong records of two uncommitted working-tree builds on that scratch;
+// round 2 re-ran the twins of commits f962206 and af9d1b8 (3 waves, 112-136 B scratch) and of this file with
+// -D'TRACE_COUNT_MIN_WAVES(L)=L::MIN_WAVES' and '=4' (profiles/r02_twin_scratch_check.txt): byte-identical to the plain kernel in
+// every run, full GPU suite green.  The sources of the two failing builds were never committed; their failing rays all sat in
+// the last 15 % of a work queue and the hit counters exceeded the stored hits (rays traced twice, others never), which points at
+// the work hand-out those experimental builds carried (guided hand-out), not at register spills.
+__global__ __launch_bounds__(TRACE_BLOCK, COUNT ? TRACE_COUNT_MIN_WAVES(Leaf) : Leaf::MIN_WAVES) void trace_kernel(LaunchParams P)
 {
   __shared__ uint2 ldsStack[TRACE_LDS_STACK + 1][TRACE_BLOCK]; // + one scratch row for the branch-free pushes
   __shared__ __attribute__((aligned(16))) float octX[TRACE_BLOCK / 64][OCT_ROWS][OCT_WORDS]; // octet node step: per-wave exchange rows

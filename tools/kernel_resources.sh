@@ -11,7 +11,7 @@ cur = None
 for line in open('/tmp/kres.log'):
     m = re.search(r'Function Name: (\S+)', line)
     if m:
-        cur = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', m.group(1)], capture_output=True, text=True).stdout.strip()
+        cur = subprocess.run(['c++filt', m.group(1)], capture_output=True, text=True).stdout.strip()
         cur = cur.replace('rtamd::dev::', '').replace('(rtamd::LaunchParams)', '').replace('void ', '')
         vals = {}
     for key in ('VGPRs', 'ScratchSize [bytes/lane]', 'LDS Size [bytes/block]', 'Occupancy [waves/SIMD]'):
