@@ -41,6 +41,32 @@ float orc_rcp(float x)
 #endif
 }
 
+/* common/math/math.h:86-97: r = rsqrtss(x); 1.5*r + ((x*-0.5)*r)*(r*r), separate multiplies and one add (intrinsics, never fused) */
+float orc_rsqrt(float x)
+{
+#if defined(__SSE__)
+  const float r = _mm_cvtss_f32(_mm_rsqrt_ss(_mm_set_ss(x)));
+  volatile float a = 1.5f * r, b = ((x * -0.5f) * r) * (r * r);
+  return a + b;
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+
+/* Vec3fa dot on an SSE4.1+ target = dpps with mask 0x7F (common/math/vec3fa.h:289-291): (x*x' + y*y') + (z*z' + 0), no fusion */
+float orc_dot3fa(const float a[3], const float b[3])
+{
+  volatile float p0 = a[0] * b[0], p1 = a[1] * b[1], p2 = a[2] * b[2];
+  volatile float s01 = p0 + p1, s23 = p2 + 0.0f;
+  return s01 + s23;
+}
+float orc_length3(const float a[3]) { return sqrtf(orc_dot3fa(a, a)); }                       /* vec3fa.h:310 */
+void orc_normalize3(const float a[3], float o[3])                                            /* vec3fa.h:311 */
+{
+  const float r = orc_rsqrt(orc_dot3fa(a, a));
+  o[0] = a[0] * r; o[1] = a[1] * r; o[2] = a[2] * r;
+}
+
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float xorf(float a, uint32_t sign) { return u2f(f2u(a) ^ sign); }

@@ -54,6 +54,17 @@ void orc_get_counters(unsigned long long out[3]);
 
 /* Arithmetic primitives, exported so that tests can compare them with oracle/_ref. */
 float orc_rcp(float x);
+float orc_rsqrt(float x);                        /* math.h:86-97 */
+float orc_dot3fa(const float a[3], const float b[3]); /* Vec3fa dot = dpps 0x7F, vec3fa.h:289-291 */
+float orc_length3(const float a[3]);             /* vec3fa.h:310 */
+void orc_normalize3(const float a[3], float o[3]); /* vec3fa.h:311 */
+/* Arithmetic of the fork's cBVH helpers (compressed.h, compressed_help.h, compressed_leaf.h).
+ * 0 (default) = the REFERENCE's: rcp / rcp_safe = rcpss + Newton step, getDelta = rcp(16), normalize / length on Vec3fa =
+ *               dpps + rsqrtss + Newton step / sqrtss - each pinned bit for bit to oracle/_ref/libref_prims.so;
+ * 1           = the PRODUCT's device arithmetic (IEEE division, exact 1/16, fma-chain squared length): regression tests that
+ *               want the HIP kernels bit for bit select this.  Not thread-safe: set it before tracing. */
+void orc_set_fork_arith(int mode);
+int orc_get_fork_arith(void);
 void orc_cross(const float a[3], const float b[3], float out[3]);
 float orc_dot(const float a[3], const float b[3]);
 void orc_stable_triangle_normal(const float a[3], const float b[3], const float c[3], float out[3]);

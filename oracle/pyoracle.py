@@ -32,6 +32,14 @@ def lib():
         L.orc_get_counters.argtypes = [vp]
         L.orc_rcp.restype = C.c_float
         L.orc_rcp.argtypes = [C.c_float]
+        for n in ("orc_rsqrt", "orc_dot3fa", "orc_length3"):
+            getattr(L, n).restype = C.c_float
+        L.orc_rsqrt.argtypes = [C.c_float]
+        L.orc_dot3fa.argtypes = [vp, vp]
+        L.orc_length3.argtypes = [vp]
+        L.orc_normalize3.argtypes = [vp, vp]
+        L.orc_set_fork_arith.argtypes = [C.c_int]
+        L.orc_get_fork_arith.restype = C.c_int
         L.orc_dot.restype = C.c_float
         L.orc_dot.argtypes = [vp, vp]
         L.orc_cross.argtypes = [vp, vp, vp]
@@ -53,8 +61,13 @@ def ref():
         vp = C.c_void_p
         R.ref_rcp.restype = C.c_float
         R.ref_rcp.argtypes = [C.c_float]
-        for n in ("ref_rcp4", "ref_rcp_safe3", "ref_zero_fix3", "ref_normalize3"):
+        for n in ("ref_rcp4", "ref_rcp_safe3", "ref_zero_fix3", "ref_normalize3", "ref_rcp_safe3f"):
             getattr(R, n).argtypes = [vp, vp]
+        for n in ("ref_rsqrt", "ref_dot3fa", "ref_length3"):
+            getattr(R, n).restype = C.c_float
+        R.ref_rsqrt.argtypes = [C.c_float]
+        R.ref_dot3fa.argtypes = [vp, vp]
+        R.ref_length3.argtypes = [vp]
         for n in ("ref_dot4", "ref_cross4"):
             getattr(R, n).argtypes = [vp, vp, vp]
         R.ref_stable_triangle_normal4.argtypes = [vp, vp, vp, vp]
@@ -136,6 +149,21 @@ class SubdivScene(TriangleScene):
             assert self.q.size % 96 == 0
             self.handle = self.L.orc_scene_new_subdiv_qbvh(self.blobs.ctypes.data, stride, self.blobs.size // stride, mode, levels,
                                                            self.q.ctypes.data, self.q.size // 96, root)
+
+
+class fork_arith:
+    """with fork_arith(1): ...  -> the cBVH helpers of the oracle use the PRODUCT's device arithmetic (bit-for-bit regression
+    checks of the HIP kernels); default 0 = the reference's rcp / rsqrt / dpps arithmetic (embree_oracle.h)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = lib().orc_get_fork_arith()
+        lib().orc_set_fork_arith(self.mode)
+
+    def __exit__(self, *a):
+        lib().orc_set_fork_arith(self.prev)
 
 
 def make_random_rays(m, lo, hi, seed=0, double_eval=False, dtype=None):

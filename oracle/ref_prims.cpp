@@ -63,7 +63,18 @@ void ref_min4of(const float* a, const float* b, const float* c, const float* d, 
 {
   vfloat4::storeu(o, min(vfloat4::loadu(a), vfloat4::loadu(b), vfloat4::loadu(c), vfloat4::loadu(d)));
 }
-// Vec3fa normalize (rsqrt based; used by the tutorials' camera and by the fork's frame construction)
+// common/math/math.h:86-97
+float ref_rsqrt(float x) { return rsqrt(x); }
+// Vec3fa dot / length (vec3fa.h:289-310): the fork's traversal measures its projected ray with these (compressed.h:498,587)
+float ref_dot3fa(const float* a, const float* b) { return dot(Vec3fa(a[0], a[1], a[2]), Vec3fa(b[0], b[1], b[2])); }
+float ref_length3(const float* x) { return length(Vec3fa(x[0], x[1], x[2])); }
+// Vec3<float> rcp_safe (vec3.h:74-80), the form intersect_frustum uses (compressed_help.h:111)
+void ref_rcp_safe3f(const float* x, float* o)
+{
+  const Vec3f r = rcp_safe(Vec3f(x[0], x[1], x[2]));
+  o[0] = r.x; o[1] = r.y; o[2] = r.z;
+}
+// Vec3fa normalize (rsqrt based; used by the tutorials' camera, the fork's frame construction and its traversal, compressed.h:499,505)
 void ref_normalize3(const float* x, float* o)
 {
   const Vec3fa r = normalize(Vec3fa(x[0], x[1], x[2]));

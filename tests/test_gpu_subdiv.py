@@ -4,13 +4,18 @@ The product tessellates on the host, encodes eager grid cells / fork cBVH blobs,
 kernels; the oracle re-traverses the SAME exported leaf records on the CPU with its own BVH and the reference's
 stack-based cBVH loop.  Bar: geomID/primID exact, t/u/v within 1e-4 relative.  Hit-count anchors are the reference
 outputs recorded in SURVEY.md section 6 (eager and compressed.grid: 162 467 of 1 M rays).
+
+The fork's cBVH modes are checked twice (helpers.check_fork_parity): byte for byte against the oracle run in the product's
+arithmetic, and at the 1e-4 tolerance against the oracle run in the REFERENCE's arithmetic (rcp = rcpss + Newton step,
+rsqrt-based normalize; pinned to the reference headers by tests/test_oracle.py).  The traversal as a whole has no
+reference-held vector: beyond the hit-count anchors these rows are "parity unpinned" (DESIGN.md section 5).
 """
 import ctypes as C
 
 import numpy as np
 import pytest
 
-from helpers import INVALID, compare_hits, fill_rays, random_rays_np
+from helpers import INVALID, check_fork_parity, compare_hits, fill_rays, random_rays_np
 
 pytestmark = pytest.mark.gpu
 
@@ -40,15 +45,23 @@ def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
     else:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
     lo, hi = verts.min(0), verts.max(0)
-    want = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
-    got = want.copy()
-    orc.intersect1M(want, nthreads=8)
+
+    def trace_oracle():
+        w = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
+        orc.intersect1M(w, nthreads=8)
+        return w
+
+    got = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
     sc.intersect1M(got)
-    nh = compare_hits(got, want, what=f"{accel} L{L} C{Cl}")
+    if accel == "default":
+        nh = compare_hits(got, trace_oracle(), what=f"{accel} L{L} C{Cl}")
+    else:
+        check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} L{L} C{Cl}")
+        nh = int((got["geomID"] != INVALID).sum())
     if (L, Cl, nrays) == (6, 3, 1_000_000) and accel in ("default", "bvh4.compressed.grid"):
         assert nh == 162_467  # reference output, SURVEY.md section 6 (eager GridSOA and compressed.grid)
     cnt = sc.intersect1M_counted(po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True))
-    assert cnt["hits"] == nh and cnt["stackSpills"] >= 0 and cnt["nodeVisits"] > 0
+    assert cnt["hits"] == nh and cnt["stackSpills"] == 0 and cnt["nodeVisits"] > 0
     # any-hit
     occ = rtc.aligned_rays(nrays)
     src = po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True)
@@ -128,13 +141,22 @@ def test_displaced_cube_with_ground_plane(rtc, po, accel):
     orc_s = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
     orc_t = po.TriangleScene(gv, gt, 0, np.full(2, g_tri, np.uint32), np.arange(2, dtype=np.uint32))
     org, d = random_rays_np(200_000, np.array([-4, -3, -4], np.float32), np.array([4, 4, 4], np.float32), 77)
-    want = rtc.aligned_rayhits(200_000)
-    fill_rays(want, org, d)
-    got = want.copy()
-    orc_t.intersect1M(want, nthreads=8)
-    orc_s.intersect1M(want, nthreads=8)
+    src = rtc.aligned_rayhits(200_000)
+    fill_rays(src, org, d)
+
+    def trace_oracle():
+        w = src.copy()
+        orc_t.intersect1M(w, nthreads=8)
+        orc_s.intersect1M(w, nthreads=8)
+        return w
+
+    got = src.copy()
     sc.intersect1M(got)
-    nh = compare_hits(got, want, what=f"displaced cube {accel}")
+    if accel == "default":
+        nh = compare_hits(got, trace_oracle(), what=f"displaced cube {accel}")
+    else:
+        check_fork_parity(po, got, trace_oracle, accel, what=f"displaced cube {accel}")
+        nh = int((got["geomID"] != INVALID).sum())
     hit_sub = int((got["geomID"] == g_sub).sum())
     assert hit_sub > 5000 and nh > hit_sub
     orc_s.free()
@@ -154,12 +176,21 @@ def test_primary_rays_config4(rtc, po, bomberman, accel):
     st = sc.stats()
     orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 3, qnodes=sc.accel_data(0), root=sc.accel_root())
     raw = rg.make_primary_rays(480, 270)
-    want = rtc.aligned_rayhits(raw.shape[0])
-    want[:] = raw.reshape(-1).view(rtc.RAYHIT_DTYPE)
-    got = want.copy()
-    orc.intersect1M(want, nthreads=8)
+    src = rtc.aligned_rayhits(raw.shape[0])
+    src[:] = raw.reshape(-1).view(rtc.RAYHIT_DTYPE)
+
+    def trace_oracle():
+        w = src.copy()
+        orc.intersect1M(w, nthreads=8)
+        return w
+
+    got = src.copy()
     sc.intersect1M(got)
-    nh = compare_hits(got, want, what=f"primary {accel}")
+    if accel == "default":
+        nh = compare_hits(got, trace_oracle(), what=f"primary {accel}")
+    else:
+        check_fork_parity(po, got, trace_oracle, accel, what=f"primary {accel}")
+        nh = int((got["geomID"] != INVALID).sum())
     assert nh > 0.7 * raw.shape[0]
     orc.free()
     sc.release()
@@ -202,11 +233,19 @@ def test_non_quad_faces_parity(rtc, po, accel):
     else:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 2)
     n = 200_000
-    want = po.make_random_rays(n, V.min(0) - 0.5, V.max(0) + 0.5, seed=8)
-    got = want.copy()
-    orc.intersect1M(want, nthreads=8)
+
+    def trace_oracle():
+        w = po.make_random_rays(n, V.min(0) - 0.5, V.max(0) + 0.5, seed=8)
+        orc.intersect1M(w, nthreads=8)
+        return w
+
+    got = po.make_random_rays(n, V.min(0) - 0.5, V.max(0) + 0.5, seed=8)
     sc.intersect1M(got)
-    nh = compare_hits(got, want, what=f"prism {accel}")
+    if accel == "default":
+        nh = compare_hits(got, trace_oracle(), what=f"prism {accel}")
+    else:
+        check_fork_parity(po, got, trace_oracle, accel, what=f"prism {accel}")
+        nh = int((got["geomID"] != INVALID).sum())
     assert nh > 0.2 * n
     hit = got["geomID"] != INVALID
     tri = hit & (got["primID"] < 2)
@@ -226,8 +265,9 @@ def test_non_quad_faces_parity(rtc, po, accel):
 
 @pytest.mark.parametrize("accel", list(ACCELS))
 def test_gpu_reproduces_the_subdiv_golden_fixture(rtc, po, bomberman, accel):
-    """The committed vectors of tests/golden/bomberman_subdiv_hits.npz (oracle on the host-built records) against the
-    kernels, without the oracle in the loop: IDs exact, t/u/v within 1e-4 relative."""
+    """The committed vectors of tests/golden/bomberman_subdiv_hits.npz (oracle in product arithmetic on the host-built
+    records; regression vectors of THIS implementation) against the kernels, without the oracle in the loop: IDs exact,
+    t/u/v within 1e-5 relative (the eager path's rcp differs between CPU vendors)."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bomberman_subdiv_hits.npz"))
     verts, fs, fi = bomberman
@@ -240,7 +280,7 @@ def test_gpu_reproduces_the_subdiv_golden_fixture(rtc, po, bomberman, accel):
     assert hit.sum() > 3000
     for f in ("tfar", "u", "v"):
         a, b = rays[f][hit].astype(np.float64), g[f"{key}_{f}"][hit].astype(np.float64)
-        assert np.all(np.abs(a - b) <= 1e-4 * np.maximum(np.abs(b), 1e-3)), f
+        assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(b), 1e-3)), f
     sc.release()
     dev.release()
 
@@ -257,10 +297,16 @@ def test_compression_levels_parity(rtc, po, bomberman, accel, L, Cl):
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
     else:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)
-    want = po.make_random_rays(200_000, verts.min(0), verts.max(0), seed=3, double_eval=True)
-    got = want.copy()
-    orc.intersect1M(want, nthreads=8)
+
+    def trace_oracle():
+        w = po.make_random_rays(200_000, verts.min(0), verts.max(0), seed=3, double_eval=True)
+        orc.intersect1M(w, nthreads=8)
+        return w
+
+    got = po.make_random_rays(200_000, verts.min(0), verts.max(0), seed=3, double_eval=True)
     sc.intersect1M(got)
-    assert compare_hits(got, want, what=f"{accel} L{L} C{Cl}") > 20_000
+    check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} L{L} C{Cl}")
+    assert int((got["geomID"] != INVALID).sum()) > 20_000
+    orc.free()
     sc.release()
     dev.release()

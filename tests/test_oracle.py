@@ -96,6 +96,38 @@ def test_primitives_match_reference_headers(po):
         assert want == min(l for x, l in vals if x == m)
 
 
+def test_fork_primitives_match_reference_headers(po):
+    """The arithmetic the fork's cBVH traversal is built from (compressed.h:498-505,587; compressed_help.h:111,156-157,252;
+    compressed_leaf.h:99-111): scalar rsqrt (rsqrtss + Newton step), Vec3fa dot (dpps) / length / normalize, Vec3f rcp_safe.
+    oracle/subdiv_oracle.inc calls the orc_* restatements; here they are compared bit for bit with the reference's own
+    headers compiled in place."""
+    R = po.ref()
+    if R is None:
+        pytest.skip("oracle/_ref/libref_prims.so not built (no reference tree)")
+    L = po.lib()
+    rng = np.random.RandomState(11)
+    o1, o2 = np.zeros(3, np.float32), np.zeros(4, np.float32)
+    for i in range(6000):
+        sc = 10.0 ** rng.uniform(-6, 6)
+        a = (rng.randn(3) * sc).astype(np.float32)
+        b = (rng.randn(3) * sc).astype(np.float32)
+        if i % 50 == 0:
+            a[rng.randint(3)] = np.float32(1e-20)  # below min_rcp_input: zero_fix path
+        x = float(np.float32(abs(a[0]) + 1e-30))
+        assert np.float32(L.orc_rsqrt(x)).tobytes() == np.float32(R.ref_rsqrt(x)).tobytes()
+        assert np.float32(L.orc_dot3fa(a.ctypes.data, b.ctypes.data)).tobytes() == np.float32(R.ref_dot3fa(a.ctypes.data, b.ctypes.data)).tobytes()
+        assert np.float32(L.orc_length3(a.ctypes.data)).tobytes() == np.float32(R.ref_length3(a.ctypes.data)).tobytes()
+        L.orc_normalize3(a.ctypes.data, o1.ctypes.data)
+        R.ref_normalize3(a.ctypes.data, o2.ctypes.data)
+        assert o1.tobytes() == o2[:3].tobytes()
+        R.ref_rcp_safe3f(a.ctypes.data, o2.ctypes.data)
+        mine = np.array([L.orc_rcp(float(v) if abs(v) >= 1e-18 else 1e-18) for v in a], np.float32)
+        assert mine.tobytes() == o2[:3].tobytes()
+    F = po.ref_fork()
+    if F is not None:  # getDelta() = rcp(16.f) of the fork's own header
+        assert np.float32(F.ref_fork_leaf_delta()).tobytes() == np.float32(L.orc_rcp(16.0)).tobytes()
+
+
 def test_block_tie_rules(po):
     """Two coplanar triangles in one Triangle4v block hit at the same t: the lowest lane wins (select_min,
     vfloat4_sse2.h:654-659); a later block with an equal t replaces the hit (T <= absDen*tfar, pluecker.h:117)."""
