@@ -37,7 +37,27 @@ void Device::parse(const std::string& cfg)
     if (key == "tri_accel" || key == "accel") tri_accel = val;
     else if (key == "subdiv_accel") subdiv_accel = val;
     else if (key == "verbose") verbose = atoi(val.c_str());
-    else if (key == "gpu" || key == "device") gpu = (val == "none") ? -1 : atoi(val.c_str());
+    else if (key == "gpu" || key == "device") { gpu = (val == "none") ? -1 : atoi(val.c_str()); gpuList.clear(); }
+    else if (key == "gpus") {
+      // "gpus=0-7" (range), "gpus=0:2:5" (list; ',' separates config keys), "gpus=0:0" (two logical shards on one GPU)
+      gpuList.clear();
+      size_t a = 0;
+      while (a <= val.size()) {
+        size_t b = val.find(':', a);
+        if (b == std::string::npos) b = val.size();
+        const std::string tok = val.substr(a, b - a);
+        const size_t dash = tok.find('-');
+        if (!tok.empty()) {
+          if (dash != std::string::npos && dash > 0) {
+            const int lo = atoi(tok.substr(0, dash).c_str()), hi = atoi(tok.substr(dash + 1).c_str());
+            for (int g = lo; g <= hi && gpuList.size() < 64; g++) gpuList.push_back(g);
+          } else
+            gpuList.push_back(atoi(tok.c_str()));
+        }
+        a = b + 1;
+      }
+      if (!gpuList.empty()) gpu = gpuList[0];
+    }
     else if (key == "threads") numThreads = atoi(val.c_str());
     else if (key == "benchmark") benchmark = atoi(val.c_str());
     else if (key == "keep_grids") keepGrids = atoi(val.c_str());
@@ -66,48 +86,84 @@ Device::Device(const char* cfg)
   int n = 0;
   HIP_CHECK(hipGetDeviceCount(&n));
   if (n <= 0) RT_THROW(RTC_ERROR_UNKNOWN, "no HIP device available: the traversal path has no CPU fallback");
-  if (gpu < 0 || gpu >= n) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpu ordinal out of range");
-  HIP_CHECK(hipSetDevice(gpu));
-  hipDeviceProp_t prop;
-  HIP_CHECK(hipGetDeviceProperties(&prop, gpu));
-  numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  ownsStream = true;
-  HIP_CHECK(hipMalloc(&countersDev, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord)));
-  for (LaunchCtx& c : launchCtx) {
-    HIP_CHECK(hipMalloc(&c.queues, 64 * 32 * 4)); // TRACE_QUEUES heads, one 128-byte line each (TRACE_QUEUE_STRIDE)
-    HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  if (gpuList.empty()) gpuList.push_back(gpu);
+  for (int g : gpuList)
+    if (g < 0 || g >= n) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpu ordinal out of range");
+  gpu = gpuList[0];
+  for (int g : gpuList) {
+    std::unique_ptr<GpuShard> sh(new GpuShard);
+    sh->ordinal = g;
+    HIP_CHECK(hipSetDevice(g));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, g));
+    sh->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_CHECK(hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking));
+    sh->ownsStream = true;
+    HIP_CHECK(hipMalloc(&sh->countersDev, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord)));
+    HIP_CHECK(hipHostMalloc((void**)&sh->overflowHost, 64, hipHostMallocMapped));
+    *sh->overflowHost = 0u;
+    HIP_CHECK(hipHostGetDevicePointer((void**)&sh->overflowDev, sh->overflowHost, 0));
+    for (LaunchCtx& c : sh->launchCtx) {
+      HIP_CHECK(hipMalloc(&c.queues, 64 * 32 * 4)); // TRACE_QUEUES heads, one 128-byte line each (TRACE_QUEUE_STRIDE)
+      HIP_CHECK(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+    }
+    if (verbose >= 1)
+      fprintf(stderr, "embree3-amd: shard %zu on device %d (%s, %d CUs), tri_accel=%s subdiv_accel=%s\n", shards.size(), g, prop.name, sh->numCUs,
+              tri_accel.c_str(), subdiv_accel.c_str());
+    shards.push_back(std::move(sh));
   }
-  if (verbose >= 1)
-    fprintf(stderr, "embree3-amd: device %d (%s, %d CUs), tri_accel=%s subdiv_accel=%s\n", gpu, prop.name, numCUs,
-            tri_accel.c_str(), subdiv_accel.c_str());
+  HIP_CHECK(hipSetDevice(gpu));
 }
 
 Device::~Device()
 {
-  if (gpu < 0) return;
-  hipSetDevice(gpu);
-  if (stream && ownsStream) {
-    hipStreamSynchronize(stream);
-    hipStreamDestroy(stream);
-  }
-  if (stageHost) hipHostFree(stageHost);
-  if (stageDev) hipFree(stageDev);
-  for (LaunchCtx& c : launchCtx) {
-    if (c.done) {
-      if (c.used) hipEventSynchronize(c.done);
-      hipEventDestroy(c.done);
+  for (auto& shp : shards) {
+    GpuShard& sh = *shp;
+    hipSetDevice(sh.ordinal);
+    if (sh.stream && sh.ownsStream) {
+      hipStreamSynchronize(sh.stream);
+      hipStreamDestroy(sh.stream);
     }
-    if (c.spill) hipFree(c.spill);
-    if (c.queues) hipFree(c.queues);
+    if (sh.stageHost) hipHostFree(sh.stageHost);
+    if (sh.stageDev) hipFree(sh.stageDev);
+    for (LaunchCtx& c : sh.launchCtx) {
+      if (c.done) {
+        if (c.used) hipEventSynchronize(c.done);
+        hipEventDestroy(c.done);
+      }
+      if (c.spill) hipFree(c.spill);
+      if (c.queues) hipFree(c.queues);
+    }
+    if (sh.countersDev) hipFree(sh.countersDev);
+    if (sh.overflowHost) hipHostFree(sh.overflowHost);
   }
-  if (countersDev) hipFree(countersDev);
 }
 
 void Device::useDevice() const
 {
-  if (gpu < 0) RT_THROW(RTC_ERROR_INVALID_OPERATION, "device was created with gpu=none: no HIP device, no traversal");
+  if (gpu < 0 || shards.empty()) RT_THROW(RTC_ERROR_INVALID_OPERATION, "device was created with gpu=none: no HIP device, no traversal");
   HIP_CHECK(hipSetDevice(gpu));
+}
+
+void Device::synchronize()
+{
+  useDevice();
+  for (auto& sh : shards) {
+    sh->use();
+    HIP_CHECK(hipStreamSynchronize(sh->stream));
+  }
+  HIP_CHECK(hipSetDevice(gpu));
+  for (auto& sh : shards) sh->checkOverflow();
+}
+
+void Device::GpuShard::use() const { HIP_CHECK(hipSetDevice(ordinal)); }
+
+void Device::GpuShard::checkOverflow()
+{
+  if (overflowHost && *(volatile uint32_t*)overflowHost != 0u) {
+    *(volatile uint32_t*)overflowHost = 0u;
+    RT_THROW(RTC_ERROR_UNKNOWN, "traversal stack overflow: a stack entry was dropped, results of the batch are incomplete");
+  }
 }
 
 void Device::setError(RTCError code, const char* msg)
@@ -127,6 +183,10 @@ void Device::setError(RTCError code, const char* msg)
 
 RTCError Device::takeError()
 {
+  // a stack overflow reported by a kernel of an asynchronous (device-resident) batch surfaces here at the latest
+  for (auto& sh : shards) {
+    try { sh->checkOverflow(); } catch (const rtc_error& e) { setError(e.code, e.msg.c_str()); }
+  }
   std::lock_guard<std::mutex> g(errMutex);
   auto it = threadErrors.find(this_thread_key());
   if (it == threadErrors.end()) return RTC_ERROR_NONE;
@@ -144,7 +204,7 @@ void Device::memoryMonitor(ssize_t bytes, bool post)
   }
 }
 
-void Device::ensureStaging(size_t bytes)
+void Device::GpuShard::ensureStaging(size_t bytes)
 {
   if (bytes <= stageBytes) return;
   size_t want = stageBytes ? stageBytes : (size_t)1 << 20;
@@ -158,9 +218,8 @@ void Device::ensureStaging(size_t bytes)
   stageBytes = want;
 }
 
-Device::LaunchCtx& Device::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther)
+Device::LaunchCtx& Device::GpuShard::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther)
 {
-  std::lock_guard<std::mutex> lock(ctxMutex);
   unsigned others = 0;
   hipStream_t otherStreams[NUM_LAUNCH_CTX];
   // first context whose last kernel has finished (back-to-back batches on one stream then cycle through two or three

@@ -38,20 +38,11 @@ struct Device : RefCounted
   RTCMemoryMonitorFunction memFn = nullptr;
   void* memFnUser = nullptr;
 
-  // HIP state
-  hipStream_t stream = nullptr;
-  bool ownsStream = false;
-  std::mutex launchMutex; // serialises host-pointer batches that share the staging buffers
-
-  // staging (host-pointer path): pinned host mirror + device batch, grown on demand
-  void* stageHost = nullptr;
-  void* stageDev = nullptr;
-  size_t stageBytes = 0;
-
-  // Per-launch scratch (work-queue heads + LDS-stack overflow area).  A ring of contexts, so that batches enqueued on
-  // DIFFERENT streams (rtcamdSetDeviceStream between calls) can be in flight together: the drain of one batch - a few
-  // deep rays keeping waves alive - then overlaps the start of the next.  A context is reused only after the kernel
-  // that last used it has finished (stream-side wait on its event, no host block).
+  // HIP state.  One GpuShard per GPU the device traces on ("gpu=<ordinal>" -> one shard; "gpus=0-7" / "gpus=0:2:5" ->
+  // several: the accel is replicated on every shard at commit and one host-pointer rtcIntersect1M / rtcOccluded1M call is
+  // split into contiguous ray ranges, one per shard, each with its own stream and staging buffers and a disjoint D2H into
+  // the caller's records - SURVEY.md section 8e; no collective).  The same ordinal may be listed twice ("gpus=0:0"): two
+  // logical shards on one GPU, which is how the sharded path is tested on a one-GPU box.
   struct LaunchCtx
   {
     void* queues = nullptr;  // TRACE_QUEUES heads, one 128-byte line each
@@ -62,10 +53,42 @@ struct Device : RefCounted
     hipStream_t stream = nullptr; // stream of the launch that last used this context
   };
   static const int NUM_LAUNCH_CTX = 8;
-  LaunchCtx launchCtx[NUM_LAUNCH_CTX];
-  unsigned nextCtx = 0;
-  std::mutex ctxMutex;
-  void* countersDev = nullptr; // wave log of the instrumented twin (one counted batch at a time)
+  struct GpuShard
+  {
+    int ordinal = 0;
+    int numCUs = 256;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    // staging (host-pointer path): pinned host mirror + device batch, grown on demand
+    void* stageHost = nullptr;
+    void* stageDev = nullptr;
+    size_t stageBytes = 0;
+    // Per-launch scratch (work-queue heads + LDS-stack overflow area).  A ring of contexts, so that batches enqueued on
+    // DIFFERENT streams (rtcamdSetDeviceStream between calls) can be in flight together: the drain of one batch - a few
+    // deep rays keeping waves alive - then overlaps the start of the next.  A context is reused only after the kernel
+    // that last used it has finished (stream-side wait on its event, no host block).
+    LaunchCtx launchCtx[NUM_LAUNCH_CTX];
+    unsigned nextCtx = 0;
+    // serialises {pick a launch context, zero its queue heads, launch, record its event}: rtcIntersect1M / rtcOccluded1M on
+    // device-resident batches are callable from several threads at once, like the reference's (rtcore.cpp:403-432)
+    std::mutex seqMutex;
+    void* countersDev = nullptr; // wave log of the instrumented twin (one counted batch at a time, under launchMutex)
+    // One word of host-mapped pinned memory the kernels set when a traversal-stack entry had to be dropped (the overflow
+    // area is sized from the tree depth, so this cannot happen for a tree the builder made; if it ever does, the call
+    // raises RTC_ERROR_UNKNOWN instead of silently missing a subtree).
+    uint32_t* overflowHost = nullptr;
+    uint32_t* overflowDev = nullptr;
+    void use() const;
+    void ensureStaging(size_t bytes);
+    // picks the next context, makes `stream` wait for its previous user; *busyOther = OTHER streams with unfinished launches.
+    // Call with seqMutex held.
+    LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther = nullptr);
+    void checkOverflow(); // throws RTC_ERROR_UNKNOWN (and clears the flag) when a kernel reported a dropped stack entry
+  };
+  std::vector<std::unique_ptr<GpuShard>> shards; // empty for gpu=none
+  std::vector<int> gpuList;                      // "gpus=" ordinals in the order given
+  GpuShard& primary() { return *shards[0]; }
+  std::mutex launchMutex; // serialises host-pointer batches (they share the staging buffers) and counted batches
 
   // Call combiner for small host-pointer calls (rtcIntersect1 / rtcOccluded1 / short 1M streams from many threads):
   // whoever finds the device idle becomes the leader and traces everything that is pending - its own call and the
@@ -89,7 +112,6 @@ struct Device : RefCounted
   std::atomic<uint64_t> statLaunches{0};      // traversal kernel launches
   std::atomic<uint64_t> statCombinedCalls{0}; // calls that went through the combiner
   std::atomic<uint64_t> statCombinedBatches{0}; // batches the combiner formed out of them
-  int numCUs = 256;
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
   uint32_t tuneOctLeaf = 0xFFFFFFFFu; // auto: 16 for triangle leaves, 24 for grid cells (measured optima);    // env RTAMD_OCT_LEAF (trace_loop.hip.h, octet leaf step; leaves that have one)
   uint32_t tuneOctSteps = 2;    // env RTAMD_OCT_STEPS
@@ -111,10 +133,8 @@ struct Device : RefCounted
   void parse(const std::string& cfg);
   void setError(RTCError code, const char* msg);
   RTCError takeError();
-  void useDevice() const; // hipSetDevice(gpu) for the calling thread
-  void ensureStaging(size_t bytes);
-  // picks the next context, makes `stream` wait for its previous user; *busyOther = OTHER streams with unfinished launches
-  LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther = nullptr);
+  void useDevice() const; // hipSetDevice(first shard) for the calling thread; throws on a gpu=none device
+  void synchronize();     // all shards' streams; raises a pending stack-overflow report
   bool tuneBlocksAuto = true; // no RTAMD_BLOCKS_PER_CU given: 2 workgroups per CU, 1 when >= 2 batches run on other streams
   void memoryMonitor(ssize_t bytes, bool post);
 };
@@ -209,12 +229,17 @@ struct Accel
   uint32_t maxDepth = 0;
   uint32_t blobStride = 0;
   size_t leafCount = 0;
-  // device copies
-  void* dNodes = nullptr;
-  void* dPrims = nullptr;
-  void* dBlobs = nullptr;
-  void* dBlobOffsets = nullptr;
-  AccelDesc desc() const;
+  // device copies, one set per shard of the device (replicated accel)
+  struct DevCopy
+  {
+    void* dNodes = nullptr;
+    void* dPrims = nullptr;
+    void* dBlobs = nullptr;
+    void* dBlobOffsets = nullptr;
+  };
+  std::vector<DevCopy> dev;
+  std::vector<int> devOrdinals; // ordinal each copy lives on (for freeDevice)
+  AccelDesc desc(size_t shard = 0) const;
   size_t deviceBytes() const;
   void upload(Device* dev);
   void freeDevice();

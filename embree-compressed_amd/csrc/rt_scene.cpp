@@ -109,13 +109,14 @@ bool Geometry::validTriangle(size_t i) const
 }
 
 // ---- Accel -------------------------------------------------------------------------------------------------
-AccelDesc Accel::desc() const
+AccelDesc Accel::desc(size_t shard) const
 {
   AccelDesc d;
-  d.nodes = (const QNode8*)dNodes;
-  d.prims = (const TriRecord*)dPrims;
-  d.blobs = (const uint8_t*)dBlobs;
-  d.blobOffsets = (const uint32_t*)dBlobOffsets;
+  const DevCopy c = shard < dev.size() ? dev[shard] : DevCopy();
+  d.nodes = (const QNode8*)c.dNodes;
+  d.prims = (const TriRecord*)c.dPrims;
+  d.blobs = (const uint8_t*)c.dBlobs;
+  d.blobOffsets = (const uint32_t*)c.dBlobOffsets;
   d.root = root;
   d.kind = kind;
   d.robust = robust;
@@ -130,11 +131,17 @@ size_t Accel::deviceBytes() const
 
 void Accel::freeDevice()
 {
-  if (dNodes) hipFree(dNodes);
-  if (dPrims) hipFree(dPrims);
-  if (dBlobs) hipFree(dBlobs);
-  if (dBlobOffsets) hipFree(dBlobOffsets);
-  dNodes = dPrims = dBlobs = dBlobOffsets = nullptr;
+  for (size_t i = 0; i < dev.size(); i++) {
+    DevCopy& c = dev[i];
+    if (!(c.dNodes || c.dPrims || c.dBlobs || c.dBlobOffsets)) continue;
+    hipSetDevice(devOrdinals[i]);
+    if (c.dNodes) hipFree(c.dNodes);
+    if (c.dPrims) hipFree(c.dPrims);
+    if (c.dBlobs) hipFree(c.dBlobs);
+    if (c.dBlobOffsets) hipFree(c.dBlobOffsets);
+  }
+  dev.clear();
+  devOrdinals.clear();
 }
 
 void Accel::clear()
@@ -149,25 +156,38 @@ void Accel::clear()
   leafCount = 0;
 }
 
-static void* upload_array(Device* dev, const void* src, size_t bytes)
+static void* upload_array(hipStream_t stream, const void* src, size_t bytes)
 {
   if (bytes == 0) return nullptr;
   void* d = nullptr;
   HIP_CHECK(hipMalloc(&d, bytes + 64)); // slack: kernels may over-read one record at the array end
-  HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, dev->stream));
+  HIP_CHECK(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, stream));
   return d;
 }
 
-void Accel::upload(Device* dev)
+// The accel is replicated: one copy per shard of the device, uploaded on the shard's own stream.
+void Accel::upload(Device* device)
 {
   freeDevice();
-  if (dev->gpu < 0) return; // host-only device: keep the host mirror for inspection
-  dev->useDevice();
-  dNodes = upload_array(dev, nodes.data(), nodes.size() * sizeof(QNode8));
-  dPrims = upload_array(dev, prims.data(), prims.size() * sizeof(TriRecord));
-  dBlobs = upload_array(dev, blobs.data(), blobs.size());
-  dBlobOffsets = upload_array(dev, blobOffsets.data(), blobOffsets.size() * 4);
-  HIP_CHECK(hipStreamSynchronize(dev->stream));
+  if (device->gpu < 0) return; // host-only device: keep the host mirror for inspection
+  device->useDevice();
+  dev.resize(device->shards.size());
+  devOrdinals.resize(device->shards.size());
+  for (size_t i = 0; i < device->shards.size(); i++) {
+    Device::GpuShard& sh = *device->shards[i];
+    sh.use();
+    devOrdinals[i] = sh.ordinal;
+    DevCopy& c = dev[i];
+    c.dNodes = upload_array(sh.stream, nodes.data(), nodes.size() * sizeof(QNode8));
+    c.dPrims = upload_array(sh.stream, prims.data(), prims.size() * sizeof(TriRecord));
+    c.dBlobs = upload_array(sh.stream, blobs.data(), blobs.size());
+    c.dBlobOffsets = upload_array(sh.stream, blobOffsets.data(), blobOffsets.size() * 4);
+  }
+  for (auto& sh : device->shards) {
+    sh->use();
+    HIP_CHECK(hipStreamSynchronize(sh->stream));
+  }
+  device->useDevice();
 }
 
 // ---- Scene ---------------------------------------------------------------------------------------------------
@@ -175,9 +195,9 @@ Scene::Scene(Device* d) : device(d) { device->retain(); }
 
 Scene::~Scene()
 {
-  if (device->gpu >= 0) hipSetDevice(device->gpu);
   triAccel.freeDevice();
   subdivAccel.freeDevice();
+  if (device->gpu >= 0) hipSetDevice(device->gpu);
   for (Geometry* g : geometries)
     if (g) g->release();
   device->release();

@@ -13,50 +13,67 @@ uint32_t trace_grid_blocks(uint32_t count, int numCUs)
   return need < resident ? (need ? need : 1u) : resident;
 }
 
-static bool is_device_pointer(const void* p)
+// -1: plain host memory; otherwise the HIP ordinal the allocation lives on
+static int pointer_device(const void* p)
 {
   hipPointerAttribute_t attr;
   hipError_t e = hipPointerGetAttributes(&attr, p);
   if (e != hipSuccess) {
     (void)hipGetLastError(); // plain (unregistered) host memory
-    return false;
+    return -1;
   }
-  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+  return (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged) ? attr.device : -1;
 }
+static bool is_device_pointer(const void* p) { return pointer_device(p) >= 0; }
 
-static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
+// One traversal launch of `A` over M records at dRays (memory of shard `si`'s GPU) on that shard's stream.
+// The calling thread's current HIP device must be the shard's (GpuShard::use()).
+static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
                       WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr)
 {
   Device* dev = s->device;
+  Device::GpuShard& sh = *dev->shards[si];
   if (A.kind == ACCEL_NONE || A.root == REF_EMPTY) return;
   LaunchParams p;
-  p.accel = A.desc();
+  p.accel = A.desc(si);
   p.rays = dRays;
   p.count = M;
   p.stride = stride;
   p.instID = instID;
   p.occluded = occluded ? 1u : 0u;
-  p.gridBlocks = trace_grid_blocks(M, dev->numCUs);
+  p.gridBlocks = trace_grid_blocks(M, sh.numCUs);
   p.poolKernel = dev->tunePoolKernel == 2u ? (M >= dev->tunePoolMinRays ? 1u : 0u) : dev->tunePoolKernel;
-  // worst-case stack: 7 siblings per level plus the entry being expanded
+  // worst-case stack: 7 siblings per level plus the entry being expanded.  The overflow area is sized for it, so a push
+  // can only be dropped if the tree is deeper than the builder reported; the kernels then raise `overflow` (below).
   const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
   size_t spillBytes;
   if (p.poolKernel) { // one overflow column per ray slot of every resident wavefront
-    p.gridBlocks = (uint32_t)dev->numCUs * TRACE_POOL_BLOCKS_PER_CU;
+    p.gridBlocks = (uint32_t)sh.numCUs * TRACE_POOL_BLOCKS_PER_CU;
     p.spillDepth = worst > (uint32_t)TRACE_POOL_STACK ? worst - TRACE_POOL_STACK : 0u;
     spillBytes = (size_t)p.gridBlocks * (TRACE_POOL_BLOCK / 64) * TRACE_POOL_SLOTS * (size_t)p.spillDepth * 8u + 16u;
   } else {
     p.spillDepth = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
     spillBytes = (size_t)p.gridBlocks * TRACE_BLOCK * (size_t)p.spillDepth * 8u + 16u;
   }
-  unsigned busyOther = 0;
-  Device::LaunchCtx& ctx = dev->acquireLaunchCtx(spillBytes, &busyOther);
-  p.spill = ctx.spill;
   p.counters = dCounters;
   p.cbvhLevels = s->compressionLevel;
-  p.numCUs = (uint32_t)dev->numCUs;
+  p.numCUs = (uint32_t)sh.numCUs;
   p.rayChunk = dev->tuneChunk;
   p.leafBatch = dev->tuneLeafBatch;
+  p.refillBatch = dev->tuneRefillBatch;
+  p.octMax = dev->tuneOctMax;
+  p.octSteps = dev->tuneOctSteps;
+  p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : ((A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER) ? 16u : 24u);
+  p.exclOffsets = exclOffsets;
+  p.exclPairs = exclPairs;
+  p.overflow = sh.overflowDev;
+  // {context, queue heads, launch, event} as one unit: concurrent callers on device-resident batches must not pick the same
+  // context (its event still reads "finished" until the new launch has recorded it).  The stream is read once.
+  std::lock_guard<std::mutex> seq(sh.seqMutex);
+  const hipStream_t stream = sh.stream;
+  unsigned busyOther = 0;
+  Device::LaunchCtx& ctx = sh.acquireLaunchCtx(spillBytes, &busyOther);
+  p.spill = ctx.spill;
   // A batch alone on the chip is fastest with two workgroups per CU; when two or more batches are running on other
   // streams a leaner grid is better: every wave pays its deepest ray's iterations, so fewer waves per batch waste fewer
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
@@ -67,16 +84,10 @@ static void launch_on(Scene* s, const Accel& A, void* dRays, uint32_t M, uint32_
   // 13.3 -> 13.8 Grays/s, shadow rays 9.3 -> 9.8, camera rays 7.1 -> 7.7)
   const uint32_t busyBlocks = A.kind == ACCEL_GRIDSOA ? 2u : 1u;
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? busyBlocks : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
-  p.refillBatch = dev->tuneRefillBatch;
-  p.octMax = dev->tuneOctMax;
-  p.octSteps = dev->tuneOctSteps;
-  p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : ((A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER) ? 16u : 24u);
   p.queues = (uint32_t*)ctx.queues;
-  p.exclOffsets = exclOffsets;
-  p.exclPairs = exclPairs;
-  HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, dev->stream));
-  HIP_CHECK(launch_trace(p, dev->stream));
-  HIP_CHECK(hipEventRecord(ctx.done, dev->stream));
+  HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, stream));
+  HIP_CHECK(launch_trace(p, stream));
+  HIP_CHECK(hipEventRecord(ctx.done, stream));
   dev->statLaunches++;
 }
 
@@ -103,6 +114,9 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
   const uint32_t instID = ctx->instID[0];
   const uint32_t recIn = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
   std::lock_guard<std::mutex> lock(dev->launchMutex);
+  // the host filter loop runs on the first shard (its rounds are latency bound, not throughput bound)
+  Device::GpuShard& sh = dev->primary();
+  sh.use();
 
   // the caller's records, on the host
   const bool devPtr = is_device_pointer(rays);
@@ -111,8 +125,8 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
   char* src = (char*)rays;
   if (devPtr) {
     mirror.resize(span);
-    HIP_CHECK(hipMemcpyAsync(mirror.data(), rays, span, hipMemcpyDeviceToHost, dev->stream));
-    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    HIP_CHECK(hipMemcpyAsync(mirror.data(), rays, span, hipMemcpyDeviceToHost, sh.stream));
+    HIP_CHECK(hipStreamSynchronize(sh.stream));
     src = mirror.data();
   }
   std::vector<RTCRayHit> W(M);
@@ -137,8 +151,8 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
     for (unsigned round = 0; !act.empty() && round < FILTER_MAX_ROUNDS; round++) {
       const uint32_t K = (uint32_t)act.size();
       const size_t bytes = (size_t)K * sizeof(RTCRayHit);
-      dev->ensureStaging(bytes);
-      RTCRayHit* h = (RTCRayHit*)dev->stageHost;
+      sh.ensureStaging(bytes);
+      RTCRayHit* h = (RTCRayHit*)sh.stageHost;
       offsets.assign(K + 1, 0);
       pairs.clear();
       for (uint32_t k = 0; k < K; k++) {
@@ -152,21 +166,21 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
       if (!pairs.empty()) {
         const size_t offBytes = ((size_t)(K + 1) * 4 + 15) & ~(size_t)15, need = offBytes + pairs.size() * sizeof(uint2);
         if (need > dExclBytes) {
-          HIP_CHECK(hipStreamSynchronize(dev->stream));
+          HIP_CHECK(hipStreamSynchronize(sh.stream));
           freeExcl();
           dExclBytes = need * 2;
           HIP_CHECK(hipMalloc(&dExcl, dExclBytes));
         }
-        HIP_CHECK(hipMemcpyAsync(dExcl, offsets.data(), (size_t)(K + 1) * 4, hipMemcpyHostToDevice, dev->stream));
-        HIP_CHECK(hipMemcpyAsync((char*)dExcl + offBytes, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, dev->stream));
+        HIP_CHECK(hipMemcpyAsync(dExcl, offsets.data(), (size_t)(K + 1) * 4, hipMemcpyHostToDevice, sh.stream));
+        HIP_CHECK(hipMemcpyAsync((char*)dExcl + offBytes, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, sh.stream));
         dOff = (const uint32_t*)dExcl;
         dPairs = (const uint2*)((char*)dExcl + offBytes);
       }
-      HIP_CHECK(hipMemcpyAsync(dev->stageDev, h, bytes, hipMemcpyHostToDevice, dev->stream));
-      launch_on(s, s->triAccel, dev->stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr, dOff, dPairs);
-      launch_on(s, s->subdivAccel, dev->stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr);
-      HIP_CHECK(hipMemcpyAsync(h, dev->stageDev, bytes, hipMemcpyDeviceToHost, dev->stream));
-      HIP_CHECK(hipStreamSynchronize(dev->stream));
+      HIP_CHECK(hipMemcpyAsync(sh.stageDev, h, bytes, hipMemcpyHostToDevice, sh.stream));
+      launch_on(s, s->triAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr, dOff, dPairs);
+      launch_on(s, s->subdivAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr);
+      HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
+      HIP_CHECK(hipStreamSynchronize(sh.stream));
       next.clear();
       for (uint32_t k = 0; k < K; k++) {
         const uint32_t i = act[k];
@@ -216,8 +230,8 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
     if (!occluded) memcpy(dst + sizeof(RTCRay), &W[i].hit, sizeof(RTCHit));
   }
   if (devPtr) {
-    HIP_CHECK(hipMemcpyAsync(rays, mirror.data(), span, hipMemcpyHostToDevice, dev->stream));
-    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    HIP_CHECK(hipMemcpyAsync(rays, mirror.data(), span, hipMemcpyHostToDevice, sh.stream));
+    HIP_CHECK(hipStreamSynchronize(sh.stream));
   }
 }
 
@@ -237,46 +251,89 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   const uint32_t instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
   const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
 
-  // instrumented twin: every wavefront stores one WaveRecord; first half of the log = triangle launch, second = subdiv
+  // instrumented twin: every wavefront stores one WaveRecord; first half of the log = triangle launch, second = subdiv.
+  // Counted batches run on ONE shard (the first, or the one the device pointer lives on) and one at a time.
   WaveRecord* dCounters = nullptr;
   WaveRecord* dCounters2 = nullptr;
   const size_t logBytes = 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord);
-  if (countersOut) {
-    dCounters = (WaveRecord*)dev->countersDev;
-    dCounters2 = dCounters + WAVE_LOG_CAPACITY;
-    HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, dev->stream));
-  }
+  std::unique_lock<std::mutex> countLock(dev->launchMutex, std::defer_lock);
+  size_t countShard = 0;
 
-  if (is_device_pointer(rays)) {
-    // device-resident stream: trace in place, stream-ordered, no host synchronisation
-    launch_on(s, s->triAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
-    launch_on(s, s->subdivAccel, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2);
-  } else {
-    std::lock_guard<std::mutex> lock(dev->launchMutex);
-    const size_t bytes = (size_t)M * rec;
-    dev->ensureStaging(bytes);
-    char* h = (char*)dev->stageHost;
-    if (byteStride == rec) memcpy(h, rays, bytes);
-    else
-      for (uint32_t i = 0; i < M; i++) memcpy(h + (size_t)i * rec, (const char*)rays + (size_t)i * byteStride, rec);
-    HIP_CHECK(hipMemcpyAsync(dev->stageDev, h, bytes, hipMemcpyHostToDevice, dev->stream));
-    launch_on(s, s->triAccel, dev->stageDev, M, rec, occluded, instID, dCounters);
-    launch_on(s, s->subdivAccel, dev->stageDev, M, rec, occluded, instID, dCounters2);
-    HIP_CHECK(hipMemcpyAsync(h, dev->stageDev, bytes, hipMemcpyDeviceToHost, dev->stream));
-    HIP_CHECK(hipStreamSynchronize(dev->stream));
-    // only tfar (byte 32) and the hit record (bytes 48..79) are outputs
-    for (uint32_t i = 0; i < M; i++) {
-      char* dst = (char*)rays + (size_t)i * byteStride;
-      const char* src = h + (size_t)i * rec;
-      memcpy(dst + 32, src + 32, 4);
-      if (!occluded) memcpy(dst + 48, src + 48, 32);
+  const int ptrDev = pointer_device(rays);
+  if (ptrDev >= 0) {
+    // device-resident stream: trace in place on the GPU the records live on, stream-ordered, no host synchronisation
+    size_t si = dev->shards.size();
+    for (size_t i = 0; i < dev->shards.size() && si == dev->shards.size(); i++)
+      if (dev->shards[i]->ordinal == ptrDev) si = i;
+    if (si == dev->shards.size()) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "the ray buffer lives on a GPU this RTCDevice does not use (gpu= / gpus=)");
+    Device::GpuShard& sh = *dev->shards[si];
+    sh.use();
+    sh.checkOverflow(); // report of an earlier asynchronous batch
+    if (countersOut) {
+      countLock.lock();
+      countShard = si;
+      dCounters = (WaveRecord*)sh.countersDev;
+      dCounters2 = dCounters + WAVE_LOG_CAPACITY;
+      HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
     }
+    launch_on(s, s->triAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
+    launch_on(s, s->subdivAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2);
+  } else {
+    // Host records: staged through pinned memory.  With several shards the M rays are split into contiguous ranges
+    // [g*M/G, (g+1)*M/G), one per shard: H2D, traversal and D2H of the ranges run concurrently on the shards' own streams
+    // and write disjoint slices of the caller's buffer (no exchange step, no collective).
+    if (!countLock.owns_lock()) countLock.lock();
+    const size_t G = (countersOut || M < 2u * dev->shards.size()) ? 1 : dev->shards.size();
+    std::vector<uint32_t> lo(G + 1);
+    for (size_t g = 0; g <= G; g++) lo[g] = (uint32_t)((uint64_t)M * g / G);
+    for (size_t g = 0; g < G; g++) {
+      Device::GpuShard& sh = *dev->shards[g];
+      const uint32_t n = lo[g + 1] - lo[g];
+      if (n == 0) continue;
+      sh.use();
+      const size_t bytes = (size_t)n * rec;
+      sh.ensureStaging(bytes);
+      char* h = (char*)sh.stageHost;
+      const char* src = (const char*)rays + (size_t)lo[g] * byteStride;
+      if (byteStride == rec) memcpy(h, src, bytes);
+      else
+        for (uint32_t i = 0; i < n; i++) memcpy(h + (size_t)i * rec, src + (size_t)i * byteStride, rec);
+      HIP_CHECK(hipMemcpyAsync(sh.stageDev, h, bytes, hipMemcpyHostToDevice, sh.stream));
+      if (countersOut) {
+        countShard = g;
+        dCounters = (WaveRecord*)sh.countersDev;
+        dCounters2 = dCounters + WAVE_LOG_CAPACITY;
+        HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
+      }
+      launch_on(s, s->triAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters);
+      launch_on(s, s->subdivAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters2);
+      HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
+    }
+    for (size_t g = 0; g < G; g++) {
+      Device::GpuShard& sh = *dev->shards[g];
+      const uint32_t n = lo[g + 1] - lo[g];
+      if (n == 0) continue;
+      sh.use();
+      HIP_CHECK(hipStreamSynchronize(sh.stream));
+      // only tfar (byte 32) and the hit record (bytes 48..79) are outputs
+      const char* h = (const char*)sh.stageHost;
+      for (uint32_t i = 0; i < n; i++) {
+        char* dst = (char*)rays + (size_t)(lo[g] + i) * byteStride;
+        const char* src = h + (size_t)i * rec;
+        memcpy(dst + 32, src + 32, 4);
+        if (!occluded) memcpy(dst + 48, src + 48, 32);
+      }
+    }
+    for (size_t g = 0; g < G; g++) dev->shards[g]->checkOverflow();
   }
 
   if (countersOut) {
     std::vector<WaveRecord> log(2 * (size_t)WAVE_LOG_CAPACITY);
-    HIP_CHECK(hipMemcpyAsync(log.data(), dCounters, logBytes, hipMemcpyDeviceToHost, dev->stream));
-    HIP_CHECK(hipStreamSynchronize(dev->stream));
+    Device::GpuShard& csh = *dev->shards[countShard];
+    csh.use();
+    HIP_CHECK(hipMemcpyAsync(log.data(), dCounters, logBytes, hipMemcpyDeviceToHost, csh.stream));
+    HIP_CHECK(hipStreamSynchronize(csh.stream));
+    csh.checkOverflow();
     TraceCounters& c = *countersOut;
     memset(&c, 0, sizeof(c));
     unsigned long long first = ~0ull;

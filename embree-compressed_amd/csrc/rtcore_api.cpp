@@ -700,7 +700,7 @@ API void rtcReleaseBVH(RTCBVH) { CATCH_BEGIN unsupported("rtcReleaseBVH"); CATCH
 // ---- MI355X extensions (include/embree3/rtcore_amd.h) -------------------------------------------------------------------
 API void* rtcamdGetDeviceStream(RTCDevice h)
 {
-  CATCH_BEGIN VERIFY(h); return (void*)D(h)->stream; CATCH_END(D(h))
+  CATCH_BEGIN VERIFY(h); D(h)->useDevice(); return (void*)D(h)->primary().stream; CATCH_END(D(h))
   return nullptr;
 }
 
@@ -710,12 +710,15 @@ API void rtcamdSetDeviceStream(RTCDevice h, void* stream)
   VERIFY(h);
   Device* d = D(h);
   d->useDevice();
-  if (d->stream && d->ownsStream) {
-    HIP_CHECK(hipStreamSynchronize(d->stream));
-    HIP_CHECK(hipStreamDestroy(d->stream));
+  // the stream of the FIRST shard: device-resident batches are traced on the GPU they live on, and a caller that manages
+  // streams itself works with one GPU per RTCDevice (one process per GPU)
+  Device::GpuShard& sh = d->primary();
+  if (sh.stream && sh.ownsStream) {
+    HIP_CHECK(hipStreamSynchronize(sh.stream));
+    HIP_CHECK(hipStreamDestroy(sh.stream));
   }
-  d->stream = (hipStream_t)stream;
-  d->ownsStream = false;
+  sh.stream = (hipStream_t)stream;
+  sh.ownsStream = false;
   CATCH_END(D(h))
 }
 
@@ -723,8 +726,7 @@ API void rtcamdSynchronizeDevice(RTCDevice h)
 {
   CATCH_BEGIN
   VERIFY(h);
-  D(h)->useDevice();
-  HIP_CHECK(hipStreamSynchronize(D(h)->stream));
+  D(h)->synchronize();
   CATCH_END(D(h))
 }
 

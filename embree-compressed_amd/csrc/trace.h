@@ -34,6 +34,8 @@ struct LaunchParams
   const uint32_t* exclOffsets;
   const uint2* exclPairs;
   uint32_t poolKernel;     // 1: ray-pool skeleton (trace_pool.hip.h), 0: lane-per-ray skeleton (trace_loop.hip.h)
+  uint32_t* overflow;      // host-mapped word, set to 1 by a kernel that had to drop a traversal-stack entry (never for a tree
+                           // whose depth the builder reported correctly: the overflow area is sized for the worst case)
 };
 
 static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)

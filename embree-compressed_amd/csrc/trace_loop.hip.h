@@ -120,6 +120,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
     else {
       if (slot - TRACE_LDS_STACK < P.spillDepth) spill[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
+      else __hip_atomic_store(P.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // entry dropped: the host raises an error
       if (COUNT) wc.spills++;
     }
   };

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(POOL_BLOCK, 2) void trace_pool_kernel(LaunchParams 
     if (pos < (uint32_t)POOL_STACK) K[pos][slot] = make_uint2(ref, dist);
     else {
       if (pos - POOL_STACK < P.spillDepth) spill_of(slot)[pos - POOL_STACK] = make_uint2(ref, dist);
+      else __hip_atomic_store(P.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // entry dropped: the host raises an error
       if (COUNT) wc.spills++;
     }
   };
