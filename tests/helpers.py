@@ -105,7 +105,7 @@ def fork_parity_stats(got, want, rtol=1e-4):
     return out
 
 
-def check_fork_parity(po, got, trace_oracle, accel, what=""):
+def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None):
     """Parity of the HIP kernels on one of the fork's cBVH modes, in two steps.
 
     trace_oracle() -> fresh oracle records for the same rays (called once per arithmetic mode).
@@ -126,6 +126,13 @@ def check_fork_parity(po, got, trace_oracle, accel, what=""):
     n = got.shape[0]
     gw, ww = got.view(np.uint32).reshape(n, -1), want_prod.view(np.uint32).reshape(n, -1)
     bad = np.unique(np.nonzero(gw != ww)[0])
+    if fork_geom is not None:
+        # scene with other geometry besides the subdivision mesh `fork_geom` (two accels traced one after the other): records
+        # that end on the other geometry follow that path's tolerance (its rcp is a hardware estimate in the oracle)
+        other = (got["geomID"][bad] != fork_geom) | (want_prod["geomID"][bad] != fork_geom)
+        if other.any():
+            compare_hits(got[bad[other]], want_prod[bad[other]], what=what + " (records on the other geometry)")
+        bad = bad[~other]
     assert len(bad) <= max(1, n // 250000), f"{what}: kernels differ from the restatement in product arithmetic on {len(bad)} records"
     if len(bad):
         compare_hits(got[bad], want_prod[bad], rtol=1e-5, what=what + " (product arithmetic)")

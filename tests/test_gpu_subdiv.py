@@ -155,7 +155,7 @@ def test_displaced_cube_with_ground_plane(rtc, po, accel):
     if accel == "default":
         nh = compare_hits(got, trace_oracle(), what=f"displaced cube {accel}")
     else:
-        check_fork_parity(po, got, trace_oracle, accel, what=f"displaced cube {accel}")
+        check_fork_parity(po, got, trace_oracle, accel, what=f"displaced cube {accel}", fork_geom=g_sub)
         nh = int((got["geomID"] != INVALID).sum())
     hit_sub = int((got["geomID"] == g_sub).sum())
     assert hit_sub > 5000 and nh > hit_sub
