@@ -115,7 +115,6 @@ struct Device : RefCounted
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
   uint32_t tuneOctLeaf = 0xFFFFFFFFu; // auto: 16 for triangle leaves, 24 for grid cells (measured optima);    // env RTAMD_OCT_LEAF (trace_loop.hip.h, octet leaf step; leaves that have one)
   uint32_t tuneOctSteps = 2;    // env RTAMD_OCT_STEPS
-  uint32_t tuneDonate = 16;     // env RTAMD_DONATE (trace_loop.hip.h, drain consolidation inside a workgroup; 0 = off)
   uint32_t tuneAloneBlocksOct = 4; // env RTAMD_ALONE_BLOCKS: workgroups per CU of a batch alone on the chip, octet-only leaf kernels
   uint32_t tuneOctMax = 16;     // env RTAMD_OCT_MAX (trace_loop.hip.h, octet node step), clamped to the build's TRACE_OCT_MAX in the kernel
   // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU).  Measured on MI355X, 1 M-ray batches:

@@ -63,7 +63,6 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;
   p.octSteps = dev->tuneOctSteps;
-  p.donateMax = dev->tuneDonate;
   p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : ((A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER) ? 16u : 24u);
   p.exclOffsets = exclOffsets;
   p.exclPairs = exclPairs;

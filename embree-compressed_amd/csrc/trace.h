@@ -27,7 +27,6 @@ struct LaunchParams
   uint32_t octSteps;       // node steps an octet stays with its ray while the queues still have rays (env RTAMD_OCT_STEPS; unlimited in the drain)
   uint32_t octLeaf;        // waiting rays from which the child-parallel leaf step runs (0 = never; env RTAMD_OCT_LEAF)
   uint32_t octMax;         // lanes with node work up to which a wave runs the child-parallel node step (0 = never; env RTAMD_OCT_MAX)
-  uint32_t donateMax;      // drain consolidation: a wave out of work with at most this many rays hands them to its workgroup (0 = off; env RTAMD_DONATE)
   uint32_t* queues;        // TRACE_QUEUES work-queue heads, zeroed on the stream before the launch
   // Filter-function re-trace (row f3): ray i skips the triangles (geomID, primID) listed in
   // exclPairs[exclOffsets[i] .. exclOffsets[i+1]) - the candidates a host filter callback rejected in earlier rounds.

@@ -79,34 +79,12 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
-// ---- drain consolidation inside a workgroup -----------------------------------------------------------------------
-// A batch of random rays is handed out in the first ~40 us of a launch; after that every wave keeps a handful of deep rays and
-// iterates with 2-10 % of its lanes for another 50-150 us - that tail was half of all wave instructions of a launch and the
-// critical path of a batch alone on the chip.  So a wave that can get no more rays from the work queues and is down to at
-// most P.donateMax active rays DONATES them to the other waves of its workgroup and exits: it writes one 12-word record per
-// ray (ray index, current node, stack pointer, hit so far) into its own - now unused - exchange rows and publishes their
-// number; the per-lane LDS stack of a donated ray stays where it is and the adopter addresses it through `col`.  Any other
-// wave of the workgroup with idle lanes ADOPTS published rays (claimed with one LDS compare-and-swap per group) before it fetches new
-// ones, reloads org / dir / tnear from the ray record and continues the ray's depth-first traversal exactly where it stopped:
-// per-ray order, arithmetic and results are unchanged (the regression tests compare byte for byte against
-// RTAMD_DONATE=0).  The wave whose exit would leave the workgroup empty stays (it is the one that drains every published ray), so
-// four sparsely filled waves become one, alone on its SIMD.
-// Control words live in the last exchange row of each wave: [0] rays published by that wave, [1] how many of them are claimed,
-// and (wave 0 only) [2] waves of the workgroup that have not left yet.
-static constexpr int OCT_USABLE = OCT_ROWS - 1; // exchange rows the octet steps / donations may use
-enum : int { CTL_COUNT = 0, CTL_TAKEN = 1, CTL_ALIVE = 2 };
-enum : int { DON_RAY = 0, DON_CUR = 1, DON_PACK = 2, DON_TFAR = 3, DON_NGX = 4, DON_NGY = 5, DON_NGZ = 6, DON_U = 7, DON_V = 8, DON_PRIM = 9, DON_GEOM = 10, DON_TRAVFAR = 11 };
-
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK], float (*octAll)[OCT_ROWS][OCT_WORDS])
+__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK], float (*octX)[OCT_WORDS])
 {
   const uint32_t tid = threadIdx.x;
-  const uint32_t wv = tid >> 6; // wave of the workgroup (wave-uniform)
-  float (*octX)[OCT_WORDS] = octAll[wv];
-  // Stack column of the ray this lane is working on: its own (tid) for rays it fetched, the DONOR lane's for rays adopted from
-  // another wave of the workgroup (drain consolidation below) - the stack stays where it is, only the ray's registers move.
-  uint32_t col = tid;
-  uint2* __restrict__ spillWG = (uint2*)P.spill + (size_t)blockIdx.x * TRACE_BLOCK * P.spillDepth; // + col * spillDepth
+  const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
+  uint2* __restrict__ spill = (uint2*)P.spill + (size_t)gthread * P.spillDepth;
   const QNode8* __restrict__ nodes = P.accel.nodes;
   uint32_t* __restrict__ queues = P.queues;
 
@@ -127,9 +105,6 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   const uint32_t wIdx = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
   const uint32_t stag = (wIdx & 3u) == 1u ? 85u : ((wIdx & 3u) == 3u ? 92u : 100u);
   bool exhausted = P.accel.root == REF_EMPTY;
-  bool lastWave = false; // this wave's exit would leave the workgroup empty: it stays and drains what the others published
-  const uint32_t donateMax = min(P.donateMax, (uint32_t)OCT_USABLE);
-  auto ctl = [&](uint32_t w) -> uint32_t* { return (uint32_t*)octAll[w][OCT_USABLE]; };
 
   WorkCounters wc;
   RayState r;
@@ -142,9 +117,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   r.hit = 0u;
 
   auto push = [&](uint32_t ref, uint32_t dist, uint32_t slot) {
-    if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][col] = make_uint2(ref, dist);
+    if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
     else {
-      uint2* spill = spillWG + (size_t)col * P.spillDepth;
       if (slot - TRACE_LDS_STACK < P.spillDepth) spill[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
       else __hip_atomic_store(P.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // entry dropped: the host raises an error
       if (COUNT) wc.spills++;
@@ -154,7 +128,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   // (merged, both become one flat access with flat latency on every pop)
   auto pop_spill = [&](uint32_t slot) -> uint2 {
     if (!(slot - TRACE_LDS_STACK < P.spillDepth)) return make_uint2(REF_EMPTY, 0x7f800000u);
-    const uint32_t* e = (const uint32_t*)(spillWG + (size_t)col * P.spillDepth + (slot - TRACE_LDS_STACK));
+    const uint32_t* e = (const uint32_t*)(spill + (slot - TRACE_LDS_STACK));
     return make_uint2(__builtin_nontemporal_load(e), __builtin_nontemporal_load(e + 1));
   };
 
@@ -177,62 +151,10 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   for (;;) {
     if (COUNT) nIter++;
     // ---- refill idle lanes ---------------------------------------------------------------------------
-    uint64_t idleMask = __ballot(!(st & ST_ACTIVE));
+    const uint64_t idleMask = __ballot(!(st & ST_ACTIVE));
     // refilling a handful of lanes costs as many instructions as refilling all 64: wait until refillBatch lanes are
     // idle (or until nothing else can run)
-    const bool wantRefill = idleMask != 0ull && (__popcll(idleMask) >= (int)P.refillBatch || idleMask == ~0ull);
-    // (a) rays other waves of this workgroup have donated (old, deep rays first: they are the batch's critical path)
-    if (wantRefill && donateMax != 0u) {
-      uint32_t pub = 0, tk = 0;
-      if (laneId < (uint32_t)(TRACE_BLOCK / 64) && laneId != wv) {
-        pub = __hip_atomic_load(&ctl(laneId)[CTL_COUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        tk = __hip_atomic_load(&ctl(laneId)[CTL_TAKEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      uint64_t have = __ballot(pub > tk);
-      if (have != 0ull) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // the records were written before their count
-      while (have != 0ull && idleMask != 0ull) {
-        const uint32_t w = (uint32_t)__builtin_ctzll(have);
-        have &= have - 1ull;
-        const uint32_t pubW = (uint32_t)__builtin_amdgcn_readlane((int)pub, (int)w);
-        const uint32_t tkW = (uint32_t)__builtin_amdgcn_readlane((int)tk, (int)w);
-        // Claim records [tkW, tkW + k) of wave w with ONE compare-and-swap on its "taken" word: it succeeds only if nobody
-        // else claimed in between, so a claim never reaches past the published count and needs no clamping afterwards.  (A
-        // fetch-and-add with a clamp of the overshoot was the first version: clang folded `first < pub ? min(k, pub - first) : 0`
-        // into an unsigned subtraction it assumed could not wrap, two racing adopters then read unpublished rows and the wild
-        // ray index faulted.)  A failed claim is simply retried at the next refill.
-        uint32_t k = min(pubW - tkW, (uint32_t)__popcll(idleMask));
-        const uint32_t first = tkW;
-        uint32_t won = 0;
-        if (laneId == 0u) {
-          uint32_t expect = tkW;
-          won = __hip_atomic_compare_exchange_strong(&ctl(w)[CTL_TAKEN], &expect, tkW + k, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-        }
-        if (__builtin_amdgcn_readfirstlane(won) == 0u) k = 0u;
-        const uint32_t myRank = lane_rank(idleMask);
-        const bool take = !(st & ST_ACTIVE) && myRank < k;
-        if (take) {
-          const float* e = octAll[w][first + myRank];
-          rayIdx = __float_as_uint(e[DON_RAY]);
-          const char* rp = (const char*)P.rays + (size_t)rayIdx * P.stride;
-          load_ray<VEC>(rp, r); // org, dir, tnear as fetched the first time; tfar / hit are the donated ones
-          cur = __float_as_uint(e[DON_CUR]);
-          const uint32_t pk = __float_as_uint(e[DON_PACK]);
-          sp = pk & 0xffffu;
-          r.hit = (pk >> 16) & 1u;
-          col = pk >> 24;
-          r.tfar = e[DON_TFAR];
-          r.ngx = e[DON_NGX]; r.ngy = e[DON_NGY]; r.ngz = e[DON_NGZ]; r.u = e[DON_U]; r.v = e[DON_V];
-          r.primID = __float_as_uint(e[DON_PRIM]); r.geomID = __float_as_uint(e[DON_GEOM]);
-          travFar = e[DON_TRAVFAR];
-          tr.init(r); // same inputs, same values as at the first fetch
-          st = ST_ACTIVE;
-          if (COUNT) raySteps = 0;
-        }
-        idleMask = __ballot(!(st & ST_ACTIVE));
-      }
-    }
-    // (b) new rays from the work queues
-    if (wantRefill && idleMask != 0ull && !exhausted) {
+    if (idleMask != 0ull && !exhausted && (__popcll(idleMask) >= (int)P.refillBatch || idleMask == ~0ull)) {
       if (poolNext == poolEnd) { // take a new chunk (one lane does the atomic, the result is wave-uniform)
         for (;;) {
           const uint32_t qLo = min(qCur * perQ, P.count);
@@ -272,7 +194,6 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           const char* rp = (const char*)P.rays + (size_t)rayIdx * P.stride;
           load_ray<VEC>(rp, r);
           r.hit = 0u;
-          col = tid;
           // stream front-end: rays with tnear > tfar are skipped (bvh_intersector_stream_filters.cpp:156);
           // occluded: already-occluded rays return early (bvh_intersector1.cpp:132-134)
           bool ok = r.tnear <= r.tfar;
@@ -290,57 +211,12 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       }
     }
     stamp(tFetch);
-    uint64_t actMask = __ballot((st & ST_ACTIVE) != 0u);
-    if (exhausted && !lastWave && (uint32_t)__popcll(actMask) <= donateMax) {
-      // No more rays from the queues and few (or no) rays left: publish them and leave, unless this is the last wave of the
-      // workgroup.  Records first, then their count, then the alive counter - whoever sees the counter reach zero sees
-      // every record (the waves of a workgroup share the LDS pipeline; the fences keep the compiler in line).
-      const uint32_t nAct = (uint32_t)__popcll(actMask);
-      if (donateMax != 0u) {
-        if (st & ST_ACTIVE) {
-          float* e = octX[lane_rank(actMask)];
-          e[DON_RAY] = __uint_as_float(rayIdx);
-          e[DON_CUR] = __uint_as_float(cur);
-          e[DON_PACK] = __uint_as_float(sp | (r.hit << 16) | (col << 24));
-          e[DON_TFAR] = r.tfar;
-          e[DON_NGX] = r.ngx; e[DON_NGY] = r.ngy; e[DON_NGZ] = r.ngz; e[DON_U] = r.u; e[DON_V] = r.v;
-          e[DON_PRIM] = __uint_as_float(r.primID); e[DON_GEOM] = __uint_as_float(r.geomID);
-          e[DON_TRAVFAR] = travFar;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        uint32_t prev = 0;
-        if (laneId == 0u) {
-          if (nAct) __hip_atomic_store(&ctl(wv)[CTL_COUNT], nAct, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          prev = __hip_atomic_fetch_sub(&ctl(0)[CTL_ALIVE], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        prev = __builtin_amdgcn_readfirstlane(prev);
-        if (prev != 1u) break; // others are still running: my rays are theirs now
-        // Last wave of the workgroup: stay.  Rays of mine that a wave claimed between my publishing and its own exit are no
-        // longer mine (it finished them or published them again under its own name): drop those lanes, keep the rest.
-        lastWave = true;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        uint32_t gone = 0;
-        if (laneId == 0u && nAct) gone = __hip_atomic_load(&ctl(wv)[CTL_TAKEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        gone = __builtin_amdgcn_readfirstlane(gone);
-        if ((st & ST_ACTIVE) && lane_rank(actMask) < gone) st = 0u;
-        actMask = __ballot((st & ST_ACTIVE) != 0u);
-      } else if (nAct == 0u)
-        break;
-    }
     if (COUNT) {
-      laneIters += (unsigned long long)__popcll(actMask);
+      laneIters += (unsigned long long)__popcll(__ballot((st & ST_ACTIVE) != 0u));
       if (st & ST_ACTIVE) { raySteps++; maxRaySteps = max(maxRaySteps, raySteps); }
     }
-    if (actMask == 0ull) {
-      if (exhausted && lastWave) {
-        // nothing to do: done unless a published ray is still unclaimed (it is adopted at the top of the next iteration)
-        uint32_t pub = 0, tk = 0;
-        if (laneId < (uint32_t)(TRACE_BLOCK / 64) && laneId != wv) {
-          pub = __hip_atomic_load(&ctl(laneId)[CTL_COUNT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          tk = __hip_atomic_load(&ctl(laneId)[CTL_TAKEN], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (__ballot(pub > tk) == 0ull) break;
-      }
+    if (__ballot((st & ST_ACTIVE) != 0u) == 0ull) {
+      if (exhausted) break;
       continue;
     }
 
@@ -349,7 +225,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     const uint64_t nodeMask = __ballot(atNode);
     const uint32_t nNode = (uint32_t)__popcll(nodeMask);
     // the octet step writes LDS stack slots only: a ray whose push could reach the overflow area takes the other path
-    const bool useOct = TRACE_OCT_MAX > 0 && nNode != 0u && nNode <= min((uint32_t)OCT_USABLE, P.octMax) &&
+    const bool useOct = TRACE_OCT_MAX > 0 && nNode != 0u && nNode <= min((uint32_t)TRACE_OCT_MAX, P.octMax) &&
                         __ballot(atNode && sp + 7u > (uint32_t)TRACE_LDS_STACK) == 0ull;
     if (useOct) {
       {
@@ -365,7 +241,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           x[7] = travFar;
           x[8] = __uint_as_float(cur);
           x[9] = __uint_as_float(sp);
-          x[10] = __uint_as_float(col);
+          x[10] = __uint_as_float(tid);
           x[11] = r.tfar;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -553,7 +429,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
             const bool h = (mask >> k) & 1u;
             const bool stacked = h && rank[k] != 0u;
             next = (h && rank[k] == 0u) ? cref[k] : next;
-            ldsStack[stacked ? top - rank[k] : (uint32_t)TRACE_LDS_STACK][col] = make_uint2(cref[k], dist[k]);
+            ldsStack[stacked ? top - rank[k] : (uint32_t)TRACE_LDS_STACK][tid] = make_uint2(cref[k], dist[k]);
           }
         } else {
 #pragma unroll
@@ -585,14 +461,14 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         // on full wavefronts, so the lanes need not wait for P.leafBatch companions: 8 waiting rays are enough.
         // (OCTET_ONLY leaves have no lane-per-ray form in this kernel: at most OCT_ROWS waiting rays go through per phase, the
         // others wait for the next one; their lane-per-ray code - 40 live registers for a grid cell - is not even compiled in)
-        if ((Leaf::OCTET_ONLY || (P.octLeaf != 0u && Leaf::octet_ok(P) && nLeaf <= (uint32_t)OCT_USABLE)) &&
+        if ((Leaf::OCTET_ONLY || (P.octLeaf != 0u && Leaf::octet_ok(P) && nLeaf <= (uint32_t)OCT_ROWS)) &&
             (nLeaf >= (Leaf::OCTET_ONLY ? max(P.octLeaf, 1u) : P.octLeaf) || !nodeWork)) {
           leafDone = true;
           if (COUNT) nLeafPhase++;
           uint32_t lid = laneId;
           asm volatile("" : "+v"(lid)); // see the node step: keeps the lane constants of this block out of the loop's live set
           const uint32_t myRow = lane_rank(leafMask);
-          const uint32_t nRows = min(nLeaf, (uint32_t)OCT_USABLE);
+          const uint32_t nRows = min(nLeaf, (uint32_t)OCT_ROWS);
           const bool inPhase = atLeafNow && myRow < nRows;
           if (inPhase) {
             if (COUNT) wc.leaves++;
@@ -651,7 +527,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         if (sp == 0) { finished = true; break; }
         sp--;
         uint2 e;
-        if (sp < (uint32_t)TRACE_LDS_STACK) e = ldsStack[sp][col];
+        if (sp < (uint32_t)TRACE_LDS_STACK) e = ldsStack[sp][tid];
         else e = pop_spill(sp);
         if (e.x == REF_EMPTY) continue;                           // entry lost to an exhausted spill area
         if (!OCCLUDED && __uint_as_float(e.y) > r.tfar) continue; // bvh_intersector1.cpp:86
@@ -712,15 +588,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, COUNT ? TRACE_COUNT_MIN_WAVES(Leaf) : 
 {
   __shared__ uint2 ldsStack[TRACE_LDS_STACK + 1][TRACE_BLOCK]; // + one scratch row for the branch-free pushes
   __shared__ __attribute__((aligned(16))) float octX[TRACE_BLOCK / 64][OCT_ROWS][OCT_WORDS]; // octet node step: per-wave exchange rows
-  if (threadIdx.x < TRACE_BLOCK / 64) { // drain consolidation: control words of each wave, waves alive
-    uint32_t* c = (uint32_t*)octX[threadIdx.x][OCT_ROWS - 1];
-    c[0] = 0u;
-    c[1] = 0u;
-    c[2] = TRACE_BLOCK / 64;
-  }
   Leaf::prepare();
-  __syncthreads();
-  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack, octX);
+  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack, octX[threadIdx.x >> 6]);
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT>

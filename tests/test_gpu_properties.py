@@ -90,8 +90,7 @@ def test_full_size_properties(rtc, bomberman, kind):
 @pytest.mark.parametrize("kind", ["tri", "tri.moeller", "bvh4.compressed.leaf", "default"])
 def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     """The child-parallel (octet) node and leaf steps (trace_loop.hip.h: 8 lanes per ray, taken when few lanes of a wave
-    have node work / from a few rays waiting at a triangle or grid-cell leaf on) against the lane-per-ray steps, the drain
-    consolidation (rays handed from wave to wave inside a workgroup) against rays that stay put, and the
+    have node work / from a few rays waiting at a triangle or grid-cell leaf on) against the lane-per-ray steps, and the
     instrumented kernel twin against the plain one: identical ray records, byte for byte, closest hit and any hit, over
     repeated runs (the ray-to-wave assignment is dynamic, so every run mixes the lanes differently).  The twin's hit counter
     must equal the number of hit records."""
@@ -119,7 +118,6 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     monkeypatch.setenv("RTAMD_KERNEL", "lane" if kind == "bvh4.compressed.leaf" else "pool")
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
     monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
-    monkeypatch.setenv("RTAMD_DONATE", "0")  # no drain consolidation: every ray stays with the wave that fetched it
     dev0, sc0 = scene()
     monkeypatch.setenv("RTAMD_KERNEL", "lane")
     ref = rays.clone()
@@ -128,19 +126,14 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     sc0.occluded1M(occ_ref)
     dev0.synchronize()
     hits = int((ref.view(torch.int32)[:, 18] != -1).sum().item())
-    # (octet node threshold, octet leaf threshold, drain consolidation: rays a wave out of work may donate to its workgroup)
-    for octmax, octleaf, donate in (("0", "0", "0"), ("8", "1", "0"), ("16", "8", "4"), ("32", "32", "31"), ("0", "0", "16"), ("16", None, None)):
+    for octmax, octleaf in (("0", "0"), ("8", "1"), ("16", "8"), ("32", "32"), ("16", None)):
         monkeypatch.setenv("RTAMD_OCT_MAX", octmax)
-        if donate is None:
-            monkeypatch.delenv("RTAMD_DONATE")  # the library's own default
-        else:
-            monkeypatch.setenv("RTAMD_DONATE", donate)
         if octleaf is None:
             monkeypatch.delenv("RTAMD_OCT_LEAF")  # the library's own default
         else:
             monkeypatch.setenv("RTAMD_OCT_LEAF", octleaf)
         dev, sc = scene()
-        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}, donate {donate}"
+        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}"
         for rep in range(2):
             got = rays.clone()
             sc.intersect1M(got)
