@@ -1,13 +1,14 @@
 """BASELINE config 5 (pathtracer): incoherent secondary rays and shadow rays that START ON the geometry, recorded
 wavefront-style from a primary pass (SURVEY.md section 8d "Config 5").  Origins on the surface are the hard case for
 parity: self-hits are avoided only by tnear (pathtracer_device.cpp uses tnear = 0.001), so GPU and oracle must agree
-on grazing and coplanar configurations.  Triangles (robust and fast path) and the eager subdivision path."""
+on grazing and coplanar configurations.  Triangles (robust and fast path), the eager subdivision path and the fork's three
+compressed modes (same-tree oracle for the order-dependent box / leaf modes, both arithmetic modes: helpers.check_fork_parity)."""
 import importlib
 
 import numpy as np
 import pytest
 
-from helpers import INVALID, compare_hits, fill_rays
+from helpers import INVALID, check_fork_parity, compare_hits, fill_rays
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +72,52 @@ def test_secondary_and_shadow_rays_from_surface_points(rtc, po, bomberman, kind)
     sc.occluded1M(sh)
     assert np.array_equal(sh["tfar"], wsh["tfar"])  # -inf where occluded, untouched elsewhere
     assert 0 < np.isneginf(sh["tfar"]).sum() < sh.shape[0]
+    orc.free()
+    sc.release()
+    dev.release()
+
+
+@pytest.mark.parametrize("accel,mode", [("bvh4.compressed.leaf", 4), ("bvh4.compressed.box", 3), ("bvh4.compressed.grid", 5)])
+def test_secondary_and_shadow_rays_on_the_compressed_accels(rtc, po, bomberman, accel, mode):
+    """Config 5 on the metric's accel family: bounce rays recorded from a 640x360 camera frame of the SAME accel, traced with
+    rtcIntersect1M; shadow rays with rtcOccluded1M, whose fork semantics are "occluded iff the outer traversal reaches a leaf"
+    (compressed.h:754-756)."""
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    verts, fs, fi = bomberman
+    dev = rtc.Device("subdiv_accel=" + accel)
+    sc = rtc.Scene(dev)
+    sc.add_subdiv(verts, fs, fi)
+    sc.set_levels(6, 3)
+    sc.commit()
+    st = sc.stats()
+    same_tree = mode in (3, 4)
+    orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], mode, 3, qnodes=sc.accel_data(0) if same_tree else None, root=sc.accel_root() if same_tree else None)
+    raw = rg.make_primary_rays(640, 360)
+    prim = rtc.aligned_rayhits(raw.shape[0])
+    prim[:] = raw.reshape(-1).view(rtc.RAYHIT_DTYPE)
+    sc.intersect1M(prim)
+    # the fork reports a dummy normal (1,0,0): bounce directions around it are as incoherent as any
+    src, sh = _bounce(rtc, prim, seed=11)
+    assert src.shape[0] > 100_000
+
+    def trace_oracle():
+        w = src.copy()
+        orc.intersect1M(w, nthreads=8)
+        return w
+
+    got = src.copy()
+    sc.intersect1M(got)
+    stt = check_fork_parity(po, got, trace_oracle, accel, what=f"secondary {accel}")
+    assert 0 < stt["hits"] < src.shape[0]
+    # shadow rays: the stub is order independent; the oracle's own full-precision tree over the blobs' bounds
+    orc.free()
+    orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], mode, 3)
+    wsh = sh.copy()
+    orc.occluded1M(wsh, nthreads=8)
+    sc.occluded1M(sh)
+    diff = int((np.isneginf(sh["tfar"]) != np.isneginf(wsh["tfar"])).sum())
+    assert diff <= max(2, sh.shape[0] // 20000), diff  # grazing rays at rounding level (product: exact blob bounds after the quantized pre-filter)
+    assert 0 < np.isneginf(sh["tfar"]).sum() <= sh.shape[0]
     orc.free()
     sc.release()
     dev.release()

@@ -197,6 +197,103 @@ def test_primary_rays_config4(rtc, po, bomberman, accel):
     dev.release()
 
 
+@pytest.mark.parametrize("accel", ["bvh4.compressed.leaf"])
+def test_primary_rays_config4_full_size(rtc, po, bomberman, accel):
+    """BASELINE config 4 at its full size: 1920x1080 camera rays of build/bomberman.ecs in 8x8 tile order on the metric's scene
+    (L6 / C3, compressed.leaf), 2 073 600 rays against the same-tree oracle, plus the one-call split used for multi-GPU
+    (contiguous ray ranges of one rtcIntersect1M call on two logical shards) which must give the same bytes."""
+    import importlib
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    verts, fs, fi = bomberman
+    dev, sc = _build(rtc, accel, verts, fs, fi, 6, 3)
+    st = sc.stats()
+    orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 3, qnodes=sc.accel_data(0), root=sc.accel_root())
+    raw = rg.make_primary_rays(1920, 1080)
+    src = rtc.aligned_rayhits(raw.shape[0])
+    src[:] = raw.reshape(-1).view(rtc.RAYHIT_DTYPE)
+
+    def trace_oracle():
+        w = src.copy()
+        orc.intersect1M(w, nthreads=16)
+        return w
+
+    got = src.copy()
+    sc.intersect1M(got)
+    stt = check_fork_parity(po, got, trace_oracle, accel, what=f"primary 1920x1080 {accel}")
+    assert stt["hits"] > 0.7 * raw.shape[0]
+    dev2 = rtc.Device(f"gpus=0:0,subdiv_accel={accel}")
+    sc2 = rtc.Scene(dev2)
+    sc2.add_subdiv(verts, fs, fi)
+    sc2.set_levels(6, 3)
+    sc2.commit()
+    again = src.copy()
+    sc2.intersect1M(again)
+    assert again.tobytes() == got.tobytes()
+    sc2.release()
+    dev2.release()
+    orc.free()
+    sc.release()
+    dev.release()
+
+
+@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf", "bvh4.compressed.box", "bvh4.compressed.grid"])
+def test_config3_displacement_geometry_scene(rtc, po, accel):
+    """BASELINE config 3 as the tutorial defines it (tutorials/displacement_geometry/displacement_geometry_device.cpp): the
+    6-quad subdivision cube at rtcSetSceneLevels(6, 4) with the Perlin-noise displacement shader (the reference's noise.cpp
+    compiled in place into oracle/_ref/libref_tutorial.so; the shader's two small functions restated in oracle/ref_tutorial.cpp),
+    RTC_SCENE_FLAG_ROBUST, ground plane = geomID 0, cube = geomID 1; rays = the tutorial's 512x512 camera frame from
+    (1.5, 1.5, -1.5) plus 1 M bbox-random rays."""
+    import importlib
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_tutorial.so")
+    if not os.path.exists(lib):
+        pytest.skip("oracle/_ref/libref_tutorial.so not built (needs the reference tree in the build container)")
+    shader = C.CDLL(lib).ref_tutorial_displacementFunction
+    rg = importlib.import_module("embree-compressed_amd.raygen")
+    v = np.array([[-1, -1, -1], [1, -1, -1], [1, -1, 1], [-1, -1, 1], [-1, 1, -1], [1, 1, -1], [1, 1, 1], [-1, 1, 1]], np.float32)
+    fi = np.array([0, 4, 5, 1, 1, 5, 6, 2, 2, 6, 7, 3, 0, 3, 7, 4, 4, 7, 6, 5, 0, 1, 2, 3], np.uint32)
+    fs = np.full(6, 4, np.uint32)
+    gv = np.array([[-10, -2, -10], [-10, -2, 10], [10, -2, -10], [10, -2, 10]], np.float32)
+    gt = np.array([[0, 1, 2], [1, 3, 2]], np.uint32)
+    L, Cl = 6, 4
+    dev = rtc.Device(f"subdiv_accel={accel}")
+    sc = rtc.Scene(dev, rtc.RTC_SCENE_FLAG_ROBUST)
+    g_tri = sc.add_triangles(gv, gt)
+    g_sub = sc.add_subdiv(v, fs, fi, level=256.0, displacement=shader)
+    assert (g_tri, g_sub) == (0, 1)
+    sc.set_levels(L, Cl)
+    sc.commit()
+    st = sc.stats()
+    same_tree = accel in ("bvh4.compressed.box", "bvh4.compressed.leaf")
+    orc_s = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0) if same_tree else None,
+                           root=sc.accel_root() if same_tree else None)
+    orc_t = po.TriangleScene(gv, gt, 0, np.full(2, g_tri, np.uint32), np.arange(2, dtype=np.uint32))
+    cam = rg.make_primary_rays(512, 512, frm=(1.5, 1.5, -1.5), to=(0, 0, 0), fov=90.0)
+    rnd = po.make_random_rays(1_000_000, np.array([-10, -2, -10], np.float32), np.array([10, 2.5, 10], np.float32), seed=2)
+    src = rtc.aligned_rayhits(cam.shape[0] + rnd.shape[0])
+    src[: cam.shape[0]] = cam.reshape(-1).view(rtc.RAYHIT_DTYPE)
+    src[cam.shape[0]:] = rnd
+
+    def trace_oracle():
+        w = src.copy()
+        orc_t.intersect1M(w, nthreads=16)  # AccelN order: accels one after the other (acceln.cpp:51-56)
+        orc_s.intersect1M(w, nthreads=16)
+        return w
+
+    got = src.copy()
+    sc.intersect1M(got)
+    if accel == "default":
+        compare_hits(got, trace_oracle(), what=f"config 3 {accel}")
+    else:
+        check_fork_parity(po, got, trace_oracle, accel, what=f"config 3 {accel}", fork_geom=g_sub)
+    hit_cam = got[: cam.shape[0]]["geomID"]
+    assert (hit_cam == g_sub).sum() > 0.25 * cam.shape[0] and (hit_cam == g_tri).sum() > 0.1 * cam.shape[0]
+    orc_s.free()
+    orc_t.free()
+    sc.release()
+    dev.release()
+
+
 def test_subdiv_modes_and_errors(rtc):
     v, fs, fi = _cube()
     # unknown accel name -> INVALID_ARGUMENT at commit (scene.cpp:511)
