@@ -68,14 +68,25 @@ def parse():
     return ap.parse_args()
 
 
+def build_hash():
+    """sha256 over the library's sources as recorded by embree-compressed_amd/Makefile at build time."""
+    try:
+        return open(os.path.join(ROOT, "embree-compressed_amd", "lib", "BUILD_HASH")).read().strip()
+    except OSError:
+        return None
+
+
 def pmc_traffic(kernel_tag, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (profiles/rNN_<workload>_pmc.json by tools/summarize_prof.py; FETCH_SIZE already doubled per the gfx950
-    correction).  bench.py cannot collect PMC counters itself; None when no summary is committed."""
+    correction).  bench.py cannot collect PMC counters itself.  A summary is used only if it was taken on a library built
+    from the same sources as the one being measured (its "build_hash"); otherwise traffic is null rather than stale."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload.replace('.', '_')}_pmc.json")))
     for path in reversed(files):
         try:
             d = json.load(open(path))
+            if d.get("build_hash") != build_hash():
+                continue
             rd = [v["read_bytes"] for k, v in d.get("FETCH_SIZE", {}).items() if kernel_tag in k and "false, false, true>" in k]
             wr = [v["write_bytes"] for k, v in d.get("WRITE_SIZE", {}).items() if kernel_tag in k and "false, false, true>" in k]
             if rd and wr:
@@ -124,9 +135,50 @@ def cpu_baseline(sc, rtc, workload, mesh, levels, lo, hi, m, budget_s):
         spent += time.perf_counter() - t0
         total += m
         reps += 1
+    one = src[: min(m, 200_000)].copy()
+    t0 = time.perf_counter()
+    orc.intersect1M(one, nthreads=1)
+    per_thread = one.shape[0] / (time.perf_counter() - t0) / 1e6
     orc.free()
+    # true-reference rates measured by the survey (the reference library built there, AVX2, 1 thread,
+    # Xeon 2.1 GHz, same scene and ray generator)
+    ref_1t = {"cbvh.leaf": 5.6, "cbvh.box": 7.0, "cbvh.grid": 7.5, "eager": 10.1, "tri": 30.4}.get(workload)
     return {"value": total / spent / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {m} rays of the same generator (seed 12345), {what} (oracle/liboracle.so), {cores} pthreads, blocks of 1024"}
+            "sample": f"{reps} x {m} rays of the same generator (seed 12345), {what} (oracle/liboracle.so), {cores} pthreads, blocks of 1024",
+            "per_thread_Mrays": per_thread,
+            "ref_ratio_note": (f"kind 'port' = scalar C restatement of the reference's AVX2 path, not the reference library (it cannot be built or "
+                               f"shipped here).  This host, 1 thread: {per_thread:.2f} Mrays/s; true reference per BASELINE.md section 2 (survey build, "
+                               f"1 thread of a 2.1 GHz Xeon, same scene and rays): {ref_1t} Mrays/s -> restatement / reference = "
+                               f"{per_thread / ref_1t:.2f} across the two machines") if ref_1t else None}
+
+
+def inflight_profile(workload):
+    """Summary of the committed rocprofv3 --kernel-trace of `bench.py --inflight 4` (profiles/rNN_<workload>_inflight.json by
+    tools/summarize_inflight.py): per-kernel durations and how many traversal kernels ran concurrently, from the start / end
+    stamps of the trace.  Same build-hash rule as pmc_traffic."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{workload.replace('.', '_')}_inflight.json")))
+    for path in reversed(files):
+        try:
+            d = json.load(open(path))
+            if d.get("build_hash") == build_hash():
+                d["source"] = os.path.relpath(path, ROOT)
+                return d
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def pcie_inclusive(sc, raygen, D, m, lo, hi, rank, reps=3):
+    """The same workload through HOST pointers: one rtcIntersect1M call over m records in pageable host memory, i.e. staging
+    copy + H2D + traversal + D2H + scatter of tfar / hit, wall clock around the call.  Reported next to `value`, never as it."""
+    best = None
+    for r in range(reps):
+        rays = np.ascontiguousarray(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, 900 + r)))
+        t0 = time.perf_counter()
+        sc.intersect1M(rays)  # uint8 [m, 80]: host pointer, 80-byte stride
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return m / best / 1e6
 
 
 def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world, occluded=False):
@@ -293,8 +345,16 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "kernel": tag,
                          "aggregate_frac_in_flight": bytes_per_ray * m * K / elapsed / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "leaf_visits_per_ray": n_prim,
-                         "inner_steps_per_ray": n_inner, "node_bytes": st["nodeBytes"], "leaf_bytes": st["primBytes"]},
+                         "inner_steps_per_ray": n_inner, "node_bytes": st["nodeBytes"], "leaf_bytes": st["primBytes"],
+                         "frac_note": "achieved / frac price ALGORITHMIC bytes (SURVEY.md 8d: every node / leaf record a ray visits, L1 / L2 hits "
+                                      "included) against the HBM peak; `traffic` is what the PMC counters saw reach HBM per launch",
+                         "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "in_flight_profile": inflight_profile(args.workload) if (m == 1_000_000 and levels == (6, 3) and args.rays_kind == "random" and not occluded) else None},
         }
+        if world == 1 and args.rays_kind == "random" and not occluded:
+            out["config"]["pcie_inclusive_Mrays"] = pcie_inclusive(sc, raygen, D, m, lo, hi, rank)
+            out["config"]["pcie_inclusive_note"] = ("one rtcIntersect1M call on pageable HOST records (staging + H2D + traversal + D2H + scatter), best of 3; "
+                                                    "`value` is the device-resident rate")
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(sc, rtc, args.workload, mesh, levels, lo, hi, m, args.cpu_seconds)
     sc.release()

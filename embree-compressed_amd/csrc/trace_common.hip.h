@@ -141,6 +141,56 @@ template <> struct TravRay<false> // node_intersector1.h:33-57, AVX2 form with o
 __device__ __forceinline__ float q2f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); } // v_cvt_f32_ubyteK
 
 // ---------------------------------------------------------------------------------------------------
+// child order of a node with exactly FOUR hit children
+// ---------------------------------------------------------------------------------------------------
+// traverseClosestHit (bvh_traverser1.h:566-635) pushes the hit children in ascending child index and sorts them on the stack:
+// two children by one compare, three by a 3-comparator network, five and more by an insertion sort - all of which visit the
+// nearer child first and, on equal distances, the HIGHER child index first (strict compares, the later push stays on top).
+// Exactly four children go through the 5-comparator network of stack_item.h:47-61,
+//   sort(s1,s2,s3,s4): if (s2<s1) xchg(s2,s1); if (s4<s3) xchg(s4,s3); if (s3<s1) xchg(s3,s1); if (s4<s2) xchg(s4,s2); if (s3<s2) xchg(s3,s2);
+// (s1 = top of stack = highest index), which is not stable: on equal distances its order differs from "higher index first"
+// in 56 of the 256 tie patterns.  Quantized nodes share planes between siblings, so equal entry distances are not exotic (the
+// first version of the kernels ranked all cases by "nearer, then higher index": 1 ray per million on the metric scene reached two
+// blobs of one patch in the other order).  sort4_network returns, for the hit child with index-order position q (0 = lowest
+// child index of the four), its visiting position (0 = entered now, 3 = visited last) exactly as that network leaves the stack.
+#define RTAMD_CX(da, qa, db, qb)                                                                    \
+  {                                                                                                  \
+    const bool sw = da < db;                                                                         \
+    const uint32_t td = sw ? db : da, tq = sw ? qb : qa;                                             \
+    db = sw ? da : db; qb = sw ? qa : qb;                                                            \
+    da = td; qa = tq;                                                                                \
+  }
+__device__ __forceinline__ uint32_t sort4_network(uint32_t e0, uint32_t e1, uint32_t e2, uint32_t e3, uint32_t q)
+{
+  uint32_t d1 = e3, d2 = e2, d3 = e1, d4 = e0; // s1 = last pushed = highest child index
+  uint32_t q1 = 3u, q2 = 2u, q3 = 1u, q4 = 0u;
+  RTAMD_CX(d2, q2, d1, q1) // if (s2.dist < s1.dist) xchg(s2, s1)
+  RTAMD_CX(d4, q4, d3, q3)
+  RTAMD_CX(d3, q3, d1, q1)
+  RTAMD_CX(d4, q4, d2, q2)
+  RTAMD_CX(d3, q3, d2, q2)
+  return q == q1 ? 0u : (q == q2 ? 1u : (q == q3 ? 2u : 3u));
+}
+#undef RTAMD_CX
+// Lane-per-ray form: ranks of the four hit children (mask has exactly four bits) re-done by the network.
+__device__ __forceinline__ void rank4_by_network(uint32_t mask, const uint32_t dist[8], uint32_t rank[8])
+{
+  uint32_t e[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t q = (uint32_t)__popc(mask & ((1u << k) - 1u));
+    const bool h = (mask >> k) & 1u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) e[j] = (h && q == (uint32_t)j) ? dist[k] : e[j];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t q = (uint32_t)__popc(mask & ((1u << k) - 1u));
+    if ((mask >> k) & 1u) rank[k] = sort4_network(e[0], e[1], e[2], e[3], q);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // triangle tests on one record; they return the un-finalized hit like PlueckerHitM / MoellerTrumboreHitM
 // ---------------------------------------------------------------------------------------------------
 struct TriHit

@@ -84,7 +84,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
 {
   const uint32_t tid = threadIdx.x;
   const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
-  uint2* __restrict__ spill = (uint2*)P.spill + (size_t)gthread * P.spillDepth;
+  // overflow column of this lane in the HBM spill area: formed where it is used (rare path) from an opaque copy of the thread
+  // index - as a loop invariant it would be hoisted and hold two VGPRs across the whole loop
+  auto spill_col = [&]() -> uint2* {
+    uint32_t g = gthread;
+    asm volatile("" : "+v"(g));
+    return (uint2*)P.spill + (size_t)g * P.spillDepth;
+  };
   const QNode8* __restrict__ nodes = P.accel.nodes;
   uint32_t* __restrict__ queues = P.queues;
 
@@ -119,7 +125,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   auto push = [&](uint32_t ref, uint32_t dist, uint32_t slot) {
     if (slot < (uint32_t)TRACE_LDS_STACK) ldsStack[slot][tid] = make_uint2(ref, dist);
     else {
-      if (slot - TRACE_LDS_STACK < P.spillDepth) spill[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
+      if (slot - TRACE_LDS_STACK < P.spillDepth) spill_col()[slot - TRACE_LDS_STACK] = make_uint2(ref, dist);
       else __hip_atomic_store(P.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // entry dropped: the host raises an error
       if (COUNT) wc.spills++;
     }
@@ -128,7 +134,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   // (merged, both become one flat access with flat latency on every pop)
   auto pop_spill = [&](uint32_t slot) -> uint2 {
     if (!(slot - TRACE_LDS_STACK < P.spillDepth)) return make_uint2(REF_EMPTY, 0x7f800000u);
-    const uint32_t* e = (const uint32_t*)(spill + (slot - TRACE_LDS_STACK));
+    const uint32_t* e = (const uint32_t*)(spill_col() + (slot - TRACE_LDS_STACK));
     return make_uint2(__builtin_nontemporal_load(e), __builtin_nontemporal_load(e + 1));
   };
 
@@ -309,6 +315,24 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
                 rank += d5 < dist + ((k ^ 5u) > k ? 1u : 0u) ? 1u : 0u;
                 rank += d6 < dist + ((k ^ 6u) > k ? 1u : 0u) ? 1u : 0u;
                 rank += m < dist + ((k ^ 7u) > k ? 1u : 0u) ? 1u : 0u;
+                // exactly four hit children with equal distances among them: the reference's 5-comparator network orders them
+                // differently (trace_common.hip.h, sort4_network); nhit is uniform within the octet
+                if (nhit == 4u) {
+                  const bool tie = h && ((d1 == dist) | (d2 == dist) | (d3 == dist) | (d4 == dist) | (d5 == dist) | (d6 == dist) | (m == dist));
+                  if (((uint32_t)(__ballot(tie) >> (lid & 56u)) & 0xffu) != 0u) { // rare
+                    uint32_t mm = mask8;
+                    const uint32_t i0 = (uint32_t)__ffs(mm) - 1u; mm &= mm - 1u;
+                    const uint32_t i1 = (uint32_t)__ffs(mm) - 1u; mm &= mm - 1u;
+                    const uint32_t i2 = (uint32_t)__ffs(mm) - 1u; mm &= mm - 1u;
+                    const uint32_t i3 = (uint32_t)__ffs(mm) - 1u;
+                    const uint32_t ob = lid & 56u; // first lane of this octet
+                    const uint32_t e0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ob + i0) << 2), (int)dist);
+                    const uint32_t e1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ob + i1) << 2), (int)dist);
+                    const uint32_t e2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ob + i2) << 2), (int)dist);
+                    const uint32_t e3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((ob + i3) << 2), (int)dist);
+                    if (h) rank = sort4_network(e0, e1, e2, e3, (uint32_t)__popc(mask8 & ((1u << k) - 1u)));
+                  }
+                }
               }
               if (nhit != 0u) {
                 const uint32_t top = oSp + nhit - 1u;
@@ -384,10 +408,15 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
         const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
         const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
-        dist[k] = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+        dist[k] = h ? __float_as_uint(tN) : ~(uint32_t)k; // non-hit: distinct sentinels -1..-8 (inline constants) above every distance, see the tie detection below
         mask |= h ? (1u << k) : 0u;
       }
       const int nhit = __popc(mask);
+#ifdef RTAMD_TRACE_RAY
+      if (rayIdx == RTAMD_TRACE_RAY)
+        printf("  GPU node %u (lane step) sp %u mask %02x dist %08x %08x %08x %08x %08x %08x %08x %08x refs %08x %08x %08x %08x %08x %08x %08x %08x tfar %a\n", cur, sp, mask,
+               dist[0], dist[1], dist[2], dist[3], dist[4], dist[5], dist[6], dist[7], cref[0], cref[1], cref[2], cref[3], cref[4], cref[5], cref[6], cref[7], r.tfar);
+#endif
       if (nhit == 0) st |= ST_POP;
       else if (nhit == 1) {
         const int k = __ffs(mask) - 1;
@@ -406,8 +435,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           for (int k = 0; k < 8; k++) rank[k] = (uint32_t)__popc(mask >> (k + 1));
         } else {
           // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
-          // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80); non-hit children carry 0xFFFFFFFF
-          // and sort behind every hit child
+          // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80; four hit children: see below); non-hit
+          // children carry sentinels above every distance and sort behind every hit child
 #pragma unroll
           for (int k = 0; k < 8; k++) rank[k] = 0;
 #pragma unroll
@@ -418,6 +447,15 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
               rank[b] += aFirst;
               rank[a] += 1u - aFirst;
             }
+          }
+          // exactly four hit children: the reference's 5-comparator network decides ties differently (trace_common.hip.h)
+          if (__ballot(nhit == 4) != 0ull) {
+            bool tie = false; // non-hit children carry distinct sentinels, so any equality is a tie between hit children
+#pragma unroll
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+              for (int b = a + 1; b < 8; b++) tie |= dist[a] == dist[b];
+            if (nhit == 4 && tie) rank4_by_network(mask, dist, rank);
           }
         }
         const uint32_t top = sp + (uint32_t)nhit - 1u;
@@ -530,6 +568,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         if (sp < (uint32_t)TRACE_LDS_STACK) e = ldsStack[sp][tid];
         else e = pop_spill(sp);
         if (e.x == REF_EMPTY) continue;                           // entry lost to an exhausted spill area
+#ifdef RTAMD_TRACE_RAY
+        if (rayIdx == RTAMD_TRACE_RAY) printf("  GPU pop sp %u ref %08x dist %08x tfar %a\n", sp, e.x, e.y, r.tfar);
+#endif
         if (!OCCLUDED && __uint_as_float(e.y) > r.tfar) continue; // bvh_intersector1.cpp:86
         cur = e.x;
         break;
@@ -540,7 +581,16 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           char* rp = (char*)P.rays + (size_t)rayIdx * P.stride;
           if (COUNT) wc.hits++;
           if (OCCLUDED) ((float*)rp)[8] = r.tfar;
-          else store_hit<VEC>(rp, r, P.instID);
+          else {
+            // leaves that report a constant normal (the fork's dummy Ng = (1,0,0), compressed.h:575,638) do not keep it in
+            // registers across the loop: three VGPRs less in the kernels that sit at the register limit
+            if constexpr (Leaf::CONST_NG) {
+              float one = 1.f, zero = 0.f;
+              asm volatile("" : "+v"(one), "+v"(zero)); // opaque: otherwise the constants are hoisted out of the loop and live (spilled) across it
+              r.ngx = one; r.ngy = zero; r.ngz = zero;
+            }
+            store_hit<VEC>(rp, r, P.instID);
+          }
         }
         st = 0u;
       }

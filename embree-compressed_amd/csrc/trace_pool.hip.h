@@ -232,7 +232,7 @@ __global__ __launch_bounds__(POOL_BLOCK, 2) void trace_pool_kernel(LaunchParams 
           const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
           const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
           const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
-          dist[k] = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+          dist[k] = h ? __float_as_uint(tN) : ~(uint32_t)k; // distinct sentinels -1..-8 (tie detection below)
           mask |= h ? (1u << k) : 0u;
         }
         const int nhit = __popc(mask);
@@ -264,6 +264,15 @@ __global__ __launch_bounds__(POOL_BLOCK, 2) void trace_pool_kernel(LaunchParams 
               }
             }
           }
+            // exactly four hit children: the reference's 5-comparator network decides ties differently (trace_common.hip.h)
+            if (__ballot(nhit == 4) != 0ull) {
+              bool tie = false; // non-hit children carry distinct sentinels, so any equality is a tie between hit children
+#pragma unroll
+              for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int b = a + 1; b < 8; b++) tie |= dist[a] == dist[b];
+              if (nhit == 4 && tie) rank4_by_network(mask, dist, rank);
+            }
           const uint32_t top = sp + (uint32_t)nhit - 1u;
           uint32_t next = REF_EMPTY;
 #pragma unroll

@@ -72,6 +72,7 @@ struct GridCellLeaf
 {
   static constexpr bool OCTET = true;
   static constexpr bool OCTET_ONLY = true; // lane kernel: cells are always tested 8 lanes per ray (intersect() below serves the ray-pool kernel)
+  static constexpr bool CONST_NG = false;
   static constexpr int MIN_WAVES = TRACE_MIN_WAVES_PER_SIMD;
   static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
   static __device__ __forceinline__ void prepare() {}
@@ -249,6 +250,9 @@ struct CbvhCtx
   float tfar;    // local tfar, shrinks with hits
   float near, zFactor;
   uint32_t special; // 0/1 in a vector register (see RayState::hit)
+#ifdef RTAMD_TRACE_RAY
+  uint32_t dbgRay; // development aid: -DRTAMD_TRACE_RAY=<index> prints the cell tests of that ray (tools/fork_diff.py)
+#endif
 };
 template <int LEVELS> struct CbvhGeom
 {
@@ -334,6 +338,11 @@ __device__ __forceinline__ bool intersect_patch(uint32_t idx, float rcp_edges, f
   const float t = (t1 * alpha + t2 * beta) / (alpha + beta);
   const float d = (t - t1) / (t2 - t1);
   const float fx = fx2 - fx1, fy = fy2 - fy1;
+#ifdef RTAMD_TRACE_RAY
+  if (c.dbgRay == RTAMD_TRACE_RAY)
+    printf("    GPU patch idx %u t1 %a t2 %a | v %a %a %a %a dz %a | box x %a %a y %a %a | org %a %a %a dir %a %a %a | p %a %a %a p2 %a %a %a | len %a %a f1 %a %a f2 %a %a | z1 %a z2 %a alpha %a beta %a t %a d %a tt %a\n",
+           idx, t1, t2, v0, v1, v2, v3, dz, blx, bhx, bly, bhy, c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, px, py, pz, p2x, p2y, p2z, lenX, lenY, fx1, fy1, fx2, fy2, z1, z2, alpha, beta, t, d, tt);
+#endif
   if (t < tt && t >= t1 && t <= t2) {
     u = (fx * d + fx1 + mx) * rcp_edges;
     v = (fy * d + fy1 + my) * rcp_edges;
@@ -510,13 +519,14 @@ template <int MODE, int LEVELS> struct CbvhLeaf
 {
   static constexpr bool OCTET = false;
   static constexpr bool OCTET_ONLY = false;
+  static constexpr bool CONST_NG = true; // dummy normal (1,0,0): written at store time by the lane kernel
   // four and five quadtree levels keep four / five parent boxes in registers: bounded at 3 waves per SIMD those kernels spill
   // 60-330 bytes per lane, so they are compiled for 2 waves per SIMD (<= 256 VGPRs) instead
   static constexpr int MIN_WAVES = LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD;
   static __device__ __forceinline__ void prepare() { cbvh_tables_init(); }
 
   template <bool OCCLUDED, bool COUNT>
-  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t)
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t rayIdxDbg)
   {
     const uint32_t idx = ref & 0x7FFFFFFFu;
     const uint8_t* blob = P.accel.blobs + (size_t)idx * P.accel.blobStride;
@@ -537,6 +547,9 @@ template <int MODE, int LEVELS> struct CbvhLeaf
     }
 
     CbvhCtx c;
+#ifdef RTAMD_TRACE_RAY
+    c.dbgRay = rayIdxDbg;
+#endif
     c.H = H;
     const uint32_t rootWord = CbvhGeom<LEVELS>::nodes(H)[0]; // requested together with the header: no extra round trip after the frustum test
     c.r = &r;
@@ -567,6 +580,9 @@ template <int MODE, int LEVELS> struct CbvhLeaf
       if (!(near <= far && near1 == near1 && far1 == far1)) return false;
     }
     c.near = near;
+#ifdef RTAMD_TRACE_RAY
+    if (rayIdxDbg == RTAMD_TRACE_RAY) printf("  GPU blob prim %u: lOrg %a %a %a lDir %a %a %a near %a far %a ray.tfar %a\n", H->primID, lox, loy, loz, ldx, ldy, ldz, near, far, r.tfar);
+#endif
 
     // projected ray between entry and exit point (:470-508)
     float tx, ty, tz;

@@ -17,6 +17,7 @@ namespace dev {
 template <bool PLUECKER> struct TriLeaf
 {
   static constexpr bool OCTET = true;
+  static constexpr bool CONST_NG = false;
   // Both forms stay in the lane kernel.  Measured with the lane-per-ray form dropped (127 VGPRs, four waves per SIMD): random
   // rays 18.0 -> 19.2 Grays/s in flight, 0.098 -> 0.089 ms alone, but rays that visit many full leaves lose: camera rays 11.4 ->
   // 10.8, bounce rays 10.3 -> 9.4, shadow rays 15.9 -> 13.2 Grays/s (8 lanes per ray test a 4-triangle leaf at half occupancy;

@@ -15,6 +15,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 #if defined(__SSE__)
 #include <xmmintrin.h>
 #endif
@@ -563,6 +564,7 @@ static void traverse_any(const onode* n, unsigned mask, uint32_t* cur, uint32_t*
   }
 }
 
+static int g_fork_trace; /* defined in subdiv_oracle.inc (debugging aid) */
 /* BVHNIntersector1<8,BVH_AN1,robust,ArrayIntersector1<...>>::intersect, bvh_intersector1.cpp:40-126 */
 static void intersect1(const orc_scene* s, orayhit* ray, uint32_t instID)
 {
@@ -577,6 +579,7 @@ static void intersect1(const orc_scene* s, orayhit* ray, uint32_t instID)
     if (sp == stack) break;
     sp--;
     uint32_t cur = sp->ptr;
+    if (g_fork_trace) printf("  CPU pop sp %d ref %08x dist %08x tfar %a\n", (int)(sp - stack), cur, sp->dist, ray->tfar);
     if (u2f(sp->dist) > ray->tfar) continue; /* :86 */
     while (1) {
       if (cur & ORC_LEAF) break;
@@ -584,6 +587,10 @@ static void intersect1(const orc_scene* s, orayhit* ray, uint32_t instID)
       g_cnt[0]++;
       const onode* n = &s->nodes[cur];
       const unsigned mask = node_test(n, &tr, robust, tNear);
+      if (g_fork_trace)
+        printf("  CPU node %u sp %d mask %02x dist %08x %08x %08x %08x %08x %08x %08x %08x refs %08x %08x %08x %08x %08x %08x %08x %08x tfar %a\n", cur, (int)(sp - stack), mask,
+               f2u(tNear[0]), f2u(tNear[1]), f2u(tNear[2]), f2u(tNear[3]), f2u(tNear[4]), f2u(tNear[5]), f2u(tNear[6]), f2u(tNear[7]),
+               n->child[0], n->child[1], n->child[2], n->child[3], n->child[4], n->child[5], n->child[6], n->child[7], ray->tfar);
       if (mask == 0) goto pop;
       traverse_closest(n, mask, tNear, &cur, &sp);
     }

@@ -65,6 +65,7 @@ void orc_normalize3(const float a[3], float o[3]); /* vec3fa.h:311 */
  *               want the HIP kernels bit for bit select this.  Not thread-safe: set it before tracing. */
 void orc_set_fork_arith(int mode);
 int orc_get_fork_arith(void);
+void orc_set_fork_trace(int on); /* debugging aid: print the cell tests of the following (single-threaded) calls */
 void orc_cross(const float a[3], const float b[3], float out[3]);
 float orc_dot(const float a[3], const float b[3]);
 void orc_stable_triangle_normal(const float a[3], const float b[3], const float c[3], float out[3]);

@@ -12,6 +12,7 @@
 //   tut_<name> <cfg> <width> <height> <out.raw> fromx fromy fromz tox toy toz [fov]
 #include "tutorials/common/tutorial/tutorial_device.h"
 #include "common/tasking/taskscheduler.h"
+#include "common/sys/sysinfo.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -63,7 +64,7 @@ int main(int argc, char** argv)
   camera.to = Vec3fa((float)atof(argv[8]), (float)atof(argv[9]), (float)atof(argv[10]));
   if (argc > 11) camera.fov = (float)atof(argv[11]);
   if (argc > 13) { g_subdivisionLevel = (unsigned)atoi(argv[12]); g_compressionLevel = (unsigned)atoi(argv[13]); }
-  TaskScheduler::create(0, false, true); // what rtcNewDevice does inside the reference's library
+  TaskScheduler::create(getNumberOfLogicalThreads(), false, true); // what rtcNewDevice does inside the reference's library (state.cpp / device.cpp)
   g_stats = (RayStats*)alignedMalloc(TaskScheduler::threadCount() * sizeof(RayStats), 64);
   for (size_t i = 0; i < TaskScheduler::threadCount(); i++) g_stats[i].numRays = 0;
   device_init(argv[1]);

@@ -105,7 +105,7 @@ def fork_parity_stats(got, want, rtol=1e-4):
     return out
 
 
-def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None):
+def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None, flip_tol=2e-5):
     """Parity of the HIP kernels on one of the fork's cBVH modes, in two steps.
 
     trace_oracle() -> fresh oracle records for the same rays (called once per arithmetic mode).
@@ -140,9 +140,10 @@ def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None):
     st = fork_parity_stats(got, want_ref)
     print(f"[parity] {what}: {st}")
     if accel.endswith("grid"):
-        assert st["hitmiss_flips"] == 0 and st["id_flips"] == 0 and st["beyond_frac"] == 0.0, (what, st)
+        lim = 0 if flip_tol <= 2e-5 else max(2, int(st["hits"] * flip_tol))  # surface-origin rays: caller widens flip_tol
+        assert st["hitmiss_flips"] <= lim and st["id_flips"] <= lim and st["beyond_frac"] == 0.0, (what, st)
     else:
-        assert st["hitmiss_flips"] <= max(2, st["hits"] // 50000), (what, st)
+        assert st["hitmiss_flips"] <= max(2, int(st["hits"] * flip_tol)), (what, st)
         assert st["id_flips"] <= max(3, st["hits"] // 10000), (what, st)
         assert st["beyond_frac"] <= 0.006, (what, st)
     return st

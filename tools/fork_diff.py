@@ -21,6 +21,17 @@ gw, ww = got.view(np.uint32).reshape(n, 20), want.view(np.uint32).reshape(n, 20)
 bad = np.unique(np.nonzero(gw != ww)[0])
 print(accel, 'L', L, 'C', C, ':', len(bad), 'records differ of', n)
 names = got.dtype.names
-for i in bad[:12]:
+import ctypes as C
+L = po.lib()
+L.orc_set_fork_trace.argtypes = [C.c_int]
+src = po.make_random_rays(n, v.min(0), v.max(0), seed=0, double_eval=True)
+for i in bad[:6]:
     cols = np.nonzero(gw[i] != ww[i])[0]
-    print('  ray', i, ' '.join('%s got %r want %r' % (names[c], got[i][names[c]], want[i][names[c]]) for c in cols))
+    print('  ray', i, ' '.join('%s got %r (%s) want %r (%s)' % (names[c], got[i][names[c]], hex(gw[i][c]), want[i][names[c]], hex(ww[i][c])) for c in cols), flush=True)
+    print('  ray record:', ' '.join(float(x).hex() for x in src[i:i + 1].view(np.float32).reshape(-1)[:9]), flush=True)
+    one = src[i:i + 1].copy()
+    with po.fork_arith(1):
+        L.orc_set_fork_trace(1)
+        orc.intersect1M(one, nthreads=1)
+        L.orc_set_fork_trace(0)
+    sys.stdout.flush()

@@ -16,8 +16,9 @@ def _demangle(names):
     return [o.replace("rtamd::dev::", "").replace("(rtamd::LaunchParams)", "").replace("void ", "") for o in out[: len(names)]]
 
 
-def kernel_metadata(lib_path):
-    """-> {demangled kernel name: {vgpr, sgpr, scratch, sgpr_spills, vgpr_spills, lds, max_wg}}"""
+def kernel_metadata(lib_path, disassemble=()):
+    """-> {demangled kernel name: {vgpr, sgpr, scratch, sgpr_spills, vgpr_spills, lds, max_wg}}; for the kernels whose demangled
+    names are listed in `disassemble` also "scratch_ops": number of scratch_load / scratch_store instructions in the ISA."""
     res = {}
     with tempfile.TemporaryDirectory() as td:
         fat = os.path.join(td, "fatbin")
@@ -48,7 +49,11 @@ def kernel_metadata(lib_path):
                     cur = {}
             names = _demangle([e.get("name", "?") for e in entries])
             for e, n in zip(entries, names):
-                res[n] = dict(vgpr=e.get("vgpr_count", 0), agpr=e.get("agpr_count", 0), sgpr=e.get("sgpr_count", 0), scratch=e.get("private_segment_fixed_size", 0),
+                ops = None
+                if n in disassemble:
+                    dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + e["name"], co], capture_output=True, text=True).stdout
+                    ops = len(re.findall(r"\bscratch_(?:load|store)", dis))
+                res[n] = dict(scratch_ops=ops, vgpr=e.get("vgpr_count", 0), agpr=e.get("agpr_count", 0), sgpr=e.get("sgpr_count", 0), scratch=e.get("private_segment_fixed_size", 0),
                               sgpr_spills=e.get("sgpr_spill_count", 0), vgpr_spills=e.get("vgpr_spill_count", 0), lds=e.get("group_segment_fixed_size", 0),
                               max_wg=e.get("max_flat_workgroup_size", 0))
     return res

@@ -22,5 +22,13 @@ for w in cbvh.leaf tri; do
   P=$R/gpurun_out/profiles_out/${TAG}_$(echo $w | tr . _)   # only gpurun_out/ travels back: copy these into profiles/ afterwards
   python3 $R/tools/summarize_prof.py $O $P
   cp $O/bench_trace.json ${P}_bench.json
+  if [ $w = cbvh.leaf ]; then
+    # the mode `value` is measured in: four batches in flight on four streams (kernel trace only: counter collection would
+    # serialise the dispatches)
+    echo "== $w: kernel trace, 4 batches in flight"
+    timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_if4 -- python3 $R/bench.py --workload $w --inflight 4 --cpu-seconds 0 --no-others --steps 40 --warmup 4 > $O/bench_if4.json 2> $O/if4.err
+    python3 $R/tools/summarize_inflight.py $O/trace_if4 ${P}_inflight.json 40
+    cp $O/bench_if4.json ${P}_inflight_bench.json
+  fi
 done
 ls -la $R/gpurun_out/profiles_out

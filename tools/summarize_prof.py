@@ -26,7 +26,12 @@ def main():
                 r = list(r)
                 r[0] = r[0][:160]
                 w.writerow(r)
-    out = {"units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch as reported by rocprofv3; *_bytes are per launch",
+    try:
+        bh = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "embree-compressed_amd", "lib", "BUILD_HASH")).read().strip()
+    except OSError:
+        bh = None
+    out = {"build_hash": bh,
+           "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch as reported by rocprofv3; *_bytes are per launch",
            "correction": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads -> read_bytes = 2 * FETCH_SIZE * 1024"}
     for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         files = glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv"))
