@@ -72,6 +72,7 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_LEAF_BATCH")) tuneLeafBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_REFILL_BATCH")) tuneRefillBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_LEAF")) tuneOctLeaf = (uint32_t)std::max(0, atoi(env));
+  if (const char* env = getenv("RTAMD_CULL")) tuneCull = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_STEPS")) tuneOctSteps = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_ALONE_BLOCKS")) tuneAloneBlocksOct = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_MAX")) tuneOctMax = (uint32_t)std::max(0, atoi(env));
@@ -132,6 +133,7 @@ Device::~Device()
         hipEventDestroy(c.done);
       }
       if (c.spill) hipFree(c.spill);
+      if (c.survivors) hipFree(c.survivors);
       if (c.queues) hipFree(c.queues);
     }
     if (sh.countersDev) hipFree(sh.countersDev);

@@ -48,6 +48,8 @@ struct Device : RefCounted
     void* queues = nullptr;  // TRACE_QUEUES heads, one 128-byte line each
     void* spill = nullptr;
     size_t spillBytes = 0;
+    void* survivors = nullptr; // root cull pre-pass: per-queue survivor lists (4 bytes per ray of the largest batch so far)
+    size_t survivorsBytes = 0;
     hipEvent_t done = nullptr;
     bool used = false;
     hipStream_t stream = nullptr; // stream of the launch that last used this context
@@ -115,6 +117,13 @@ struct Device : RefCounted
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
   uint32_t tuneOctLeaf = 0xFFFFFFFFu; // auto: 16 for triangle leaves, 24 for grid cells (measured optima);    // env RTAMD_OCT_LEAF (trace_loop.hip.h, octet leaf step; leaves that have one)
   uint32_t tuneOctSteps = 2;    // env RTAMD_OCT_STEPS
+  // env RTAMD_CULL=1: root cull pre-pass in front of the lane kernel (trace_cull.hip.h).  OFF by default: measured on MI355X
+  // (profiles/r02_cull_ab.txt) it removes 17 % of the wave instructions of a 1 M-ray batch (40.8 M -> 6.0 M + 27.8 M) but the
+  // traversal kernel, fed with survivors only, takes longer (158 -> 24 + 181 us alone) and four batches in flight gain nothing
+  // (cbvh.leaf +0.7 %, triangles +5 %, eager -12 %): the kernels are bound by dependent latency at three waves per SIMD, not by
+  // instruction issue.
+  uint32_t tuneCull = 0;
+  uint32_t tuneCullMinRays = 65536; // batches below this size go straight to the traversal kernel (the extra launch costs ~5 us)
   uint32_t tuneAloneBlocksOct = 4; // env RTAMD_ALONE_BLOCKS: workgroups per CU of a batch alone on the chip, octet-only leaf kernels
   uint32_t tuneOctMax = 16;     // env RTAMD_OCT_MAX (trace_loop.hip.h, octet node step), clamped to the build's TRACE_OCT_MAX in the kernel
   // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU).  Measured on MI355X, 1 M-ray batches:

@@ -28,8 +28,10 @@ static bool is_device_pointer(const void* p) { return pointer_device(p) >= 0; }
 
 // One traversal launch of `A` over M records at dRays (memory of shard `si`'s GPU) on that shard's stream.
 // The calling thread's current HIP device must be the shard's (GpuShard::use()).
+// cullCountsOut (counted batches): host buffer of TRACE_QUEUES * TRACE_QUEUE_STRIDE words that receives the launch's queue words
+// after the kernels (word 1 of a queue = rays that survived the root cull pre-pass, word 2 = valid rays the pre-pass tested)
 static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
-                      WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr)
+                      WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr, uint32_t* cullCountsOut = nullptr)
 {
   Device* dev = s->device;
   Device::GpuShard& sh = *dev->shards[si];
@@ -85,8 +87,26 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   const uint32_t busyBlocks = A.kind == ACCEL_GRIDSOA ? 2u : 1u;
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? busyBlocks : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.queues = (uint32_t*)ctx.queues;
-  HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, stream));
+  // Root cull pre-pass (trace_cull.hip.h): large batches on the lane kernel whose root is an inner node.  Filter re-traces
+  // (exclusion lists) are small and skip it.
+  p.survivors = nullptr;
+  if (dev->tuneCull && !p.poolKernel && !exclOffsets && M >= dev->tuneCullMinRays && !(A.root & REF_LEAF)) {
+    const size_t need = ((size_t)(M + TRACE_QUEUES - 1) / TRACE_QUEUES) * TRACE_QUEUES * 4u;
+    if (need > ctx.survivorsBytes) { // first batch of this size on this context (an allocation synchronises the device)
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (ctx.survivors) HIP_CHECK(hipFree(ctx.survivors));
+      ctx.survivors = nullptr;
+      ctx.survivorsBytes = 0;
+      HIP_CHECK(hipMalloc(&ctx.survivors, need + need / 4));
+      ctx.survivorsBytes = need + need / 4;
+    }
+    p.survivors = (uint32_t*)ctx.survivors;
+  }
+  HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, stream)); // heads, survivor counts, valid-ray counts
+  if (p.survivors) HIP_CHECK(launch_cull(p, stream));
   HIP_CHECK(launch_trace(p, stream));
+  if (cullCountsOut && p.survivors) HIP_CHECK(hipMemcpyAsync(cullCountsOut, ctx.queues, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, hipMemcpyDeviceToHost, stream));
+  else if (cullCountsOut) memset(cullCountsOut, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4);
   HIP_CHECK(hipEventRecord(ctx.done, stream));
   dev->statLaunches++;
 }
@@ -258,6 +278,13 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   const size_t logBytes = 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord);
   std::unique_lock<std::mutex> countLock(dev->launchMutex, std::defer_lock);
   size_t countShard = 0;
+  std::vector<uint32_t> cullWords; // counted batches: queue words of the triangle launch, then of the subdivision launch
+  uint32_t *cull1 = nullptr, *cull2 = nullptr;
+  if (countersOut) {
+    cullWords.assign(2 * (size_t)TRACE_QUEUES * TRACE_QUEUE_STRIDE, 0u);
+    cull1 = cullWords.data();
+    cull2 = cull1 + (size_t)TRACE_QUEUES * TRACE_QUEUE_STRIDE;
+  }
 
   const int ptrDev = pointer_device(rays);
   if (ptrDev >= 0) {
@@ -276,8 +303,8 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
       dCounters2 = dCounters + WAVE_LOG_CAPACITY;
       HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
     }
-    launch_on(s, s->triAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters);
-    launch_on(s, s->subdivAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2);
+    launch_on(s, s->triAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters, nullptr, nullptr, cull1);
+    launch_on(s, s->subdivAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2, nullptr, nullptr, cull2);
   } else {
     // Host records: staged through pinned memory.  With several shards the M rays are split into contiguous ranges
     // [g*M/G, (g+1)*M/G), one per shard: H2D, traversal and D2H of the ranges run concurrently on the shards' own streams
@@ -305,8 +332,8 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
         dCounters2 = dCounters + WAVE_LOG_CAPACITY;
         HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
       }
-      launch_on(s, s->triAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters);
-      launch_on(s, s->subdivAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters2);
+      launch_on(s, s->triAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters, nullptr, nullptr, cull1);
+      launch_on(s, s->subdivAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters2, nullptr, nullptr, cull2);
       HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
     }
     for (size_t g = 0; g < G; g++) {
@@ -352,6 +379,19 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
       c.drainTicksMax = std::max(c.drainTicksMax, w.end - w.lastGrab);
       c.waveEndHist[std::min<unsigned long long>((w.end - first) / 400ull, 63ull)] += 1; // 4 us buckets of 10 ns ticks
       c.waveIterHist[std::min<unsigned long long>(w.iterations / 2ull, 63ull)] += 1;
+    }
+    // root cull pre-pass: it visited the root once for every valid ray; the traversal kernel saw (and counted) the survivors only
+    for (int l = 0; l < 2; l++) {
+      unsigned long long survivors = 0, valid = 0;
+      for (int q = 0; q < TRACE_QUEUES; q++) {
+        survivors += cullWords[((size_t)l * TRACE_QUEUES + q) * TRACE_QUEUE_STRIDE + 1];
+        valid += cullWords[((size_t)l * TRACE_QUEUES + q) * TRACE_QUEUE_STRIDE + 2];
+      }
+      if (valid) {
+        c.rays += valid - survivors;
+        c.nodeVisits += valid;
+        c.reserved += survivors; // rays that survived the root cull (reported as `cullSurvivors` by the Python binding)
+      }
     }
   }
 }

@@ -34,6 +34,12 @@ struct LaunchParams
   const uint32_t* exclOffsets;
   const uint2* exclPairs;
   uint32_t poolKernel;     // 1: ray-pool skeleton (trace_pool.hip.h), 0: lane-per-ray skeleton (trace_loop.hip.h)
+  // Root cull pass (trace_cull.hip.h): when `survivors` is set, a streaming pre-pass has tested every ray against the root node's
+  // children and appended the indices of the rays that hit at least one of them to per-work-queue lists: queue q's list starts
+  // at survivors[q * perQ] (perQ = ceil(count / TRACE_QUEUES), its capacity) and holds queues[q * TRACE_QUEUE_STRIDE + 1] entries;
+  // queues[q * TRACE_QUEUE_STRIDE + 2] counts the valid rays of the queue's range (for the work counters).  The traversal kernel
+  // then fetches rays through the lists.  nullptr: rays are fetched by index (no pre-pass).
+  uint32_t* survivors;
   uint32_t* overflow;      // host-mapped word, set to 1 by a kernel that had to drop a traversal-stack entry (never for a tree
                            // whose depth the builder reported correctly: the overflow area is sized for the worst case)
 };
@@ -63,6 +69,7 @@ uint32_t trace_grid_blocks(uint32_t count, int numCUs);
 
 // Enqueue traversal of one batch on `stream`.  Asynchronous; errors surface through the returned hipError_t.
 hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream);    // trace_tri.hip
+hipError_t launch_cull(const LaunchParams& p, hipStream_t stream);         // trace_tri.hip (trace_cull.hip.h): root cull pre-pass
 hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream); // trace_subdiv.hip
 inline hipError_t launch_trace(const LaunchParams& p, hipStream_t stream)
 {

@@ -141,6 +141,43 @@ template <> struct TravRay<false> // node_intersector1.h:33-57, AVX2 form with o
 __device__ __forceinline__ float q2f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); } // v_cvt_f32_ubyteK
 
 // ---------------------------------------------------------------------------------------------------
+// does the ray hit any child of this node?  Same decode and slab arithmetic as the lane-per-ray node step of trace_loop.hip.h
+// (a child counts iff tN <= tF there), used by the root cull pre-pass (trace_cull.hip.h).
+// ---------------------------------------------------------------------------------------------------
+template <bool ROBUST> __device__ __forceinline__ bool node_any_child_hit(const QNode8* node, const TravRay<ROBUST>& tr, float travFar)
+{
+  const uint4* np = (const uint4*)node;
+  const uint4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4], n5 = np[5];
+  const float ox = __uint_as_float(n0.x), oy = __uint_as_float(n0.y), oz = __uint_as_float(n0.z);
+  const float sx = __uint_as_float((n0.w & 0xffu) << 23);
+  const float sy = __uint_as_float(((n0.w >> 8) & 0xffu) << 23);
+  const float sz = __uint_as_float(((n0.w >> 16) & 0xffu) << 23);
+  const bool ngx = tr.negx(), ngy = tr.negy(), ngz = tr.negz();
+  const uint32_t nx0 = ngx ? n3.z : n3.x, nx1 = ngx ? n3.w : n3.y;
+  const uint32_t fx0 = ngx ? n3.x : n3.z, fx1 = ngx ? n3.y : n3.w;
+  const uint32_t ny0 = ngy ? n4.z : n4.x, ny1 = ngy ? n4.w : n4.y;
+  const uint32_t fy0 = ngy ? n4.x : n4.z, fy1 = ngy ? n4.y : n4.w;
+  const uint32_t nz0 = ngz ? n5.z : n5.x, nz1 = ngz ? n5.w : n5.y;
+  const uint32_t fz0 = ngz ? n5.x : n5.z, fz1 = ngz ? n5.y : n5.w;
+  const uint32_t cref[8] = {n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int kk = k & 3;
+    const float npx = madd(q2f(k < 4 ? nx0 : nx1, kk), sx, ox);
+    const float npy = madd(q2f(k < 4 ? ny0 : ny1, kk), sy, oy);
+    const float npz = madd(q2f(k < 4 ? nz0 : nz1, kk), sz, oz);
+    const float fpx = madd(q2f(k < 4 ? fx0 : fx1, kk), sx, ox);
+    const float fpy = madd(q2f(k < 4 ? fy0 : fy1, kk), sy, oy);
+    const float fpz = madd(q2f(k < 4 ? fz0 : fz1, kk), sz, oz);
+    const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
+    const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
+    any |= (tN <= tF) & (cref[k] != REF_EMPTY);
+  }
+  return any;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // child order of a node with exactly FOUR hit children
 // ---------------------------------------------------------------------------------------------------
 // traverseClosestHit (bvh_traverser1.h:566-635) pushes the hit children in ascending child index and sorts them on the stack:

@@ -100,6 +100,14 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   // and, when that is drained, finds the next non-empty queue with ONE vector load of all heads.
   const uint32_t perQ = (P.count + (uint32_t)TRACE_QUEUES - 1u) / (uint32_t)TRACE_QUEUES;
   const uint32_t laneId = lane_rank(~0ull);
+  // Entries queue q hands out: its share of the batch, or - after the root cull pre-pass (trace_cull.hip.h) - the survivors the
+  // pre-pass appended to the queue's list (count next to the queue head); the entries are then ray indices read from the list.
+  const uint32_t* __restrict__ survivors = P.survivors;
+  auto queue_len = [&](uint32_t q) -> uint32_t {
+    if (survivors) return __hip_atomic_load(&queues[q * QUEUE_STRIDE + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lo = min(q * perQ, P.count);
+    return min(lo + perQ, P.count) - lo;
+  };
   uint32_t qCur = (blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6)) & (uint32_t)(TRACE_QUEUES - 1); // wave-uniform
   uint32_t poolNext = 0, poolEnd = 0; // wave-uniform: rays [poolNext, poolEnd) belong to this wave
   // Staggered exhaustion: a quarter of the waves treats a queue as closed once 85 % of it are handed out, another quarter
@@ -163,31 +171,31 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     if (idleMask != 0ull && !exhausted && (__popcll(idleMask) >= (int)P.refillBatch || idleMask == ~0ull)) {
       if (poolNext == poolEnd) { // take a new chunk (one lane does the atomic, the result is wave-uniform)
         for (;;) {
-          const uint32_t qLo = min(qCur * perQ, P.count);
-          const uint32_t qHi = min(qLo + perQ, P.count);
+          const uint32_t qLo = qCur * perQ; // first entry of the queue (ray index, or position in the survivor lists)
+          const uint32_t qLen = queue_len(qCur);
           uint32_t base = 0xFFFFFFFFu;
           bool open = true;
           if (stag != 100u) { // this wave treats the queue as closed once `stag` percent of it are handed out
             uint32_t pre = 0;
             if (laneId == 0u) pre = __hip_atomic_load(&queues[qCur * QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             pre = __builtin_amdgcn_readfirstlane(pre);
-            open = pre < (uint32_t)((uint64_t)(qHi - qLo) * stag / 100u);
+            open = pre < (uint32_t)((uint64_t)qLen * stag / 100u);
           }
           if (open) {
             if (laneId == 0u) base = atomicAdd(&queues[qCur * QUEUE_STRIDE], P.rayChunk);
             base = __builtin_amdgcn_readfirstlane(base);
           }
-          if (base < qHi - qLo) {
+          if (base < qLen) {
             if (COUNT) rtLastGrab = __builtin_amdgcn_s_memrealtime();
             poolNext = qLo + base;
-            poolEnd = min(poolNext + P.rayChunk, qHi);
+            poolEnd = min(poolNext + P.rayChunk, qLo + qLen);
             break;
           }
           // drained: lane l reads head l (heads only grow, so a stale value can only under-report "drained"), the
           // ballot marks the queues that still have rays, take the next one cyclically after qCur
-          const uint32_t myLo = min(laneId * perQ, P.count), myHi = min(myLo + perQ, P.count);
           const uint32_t head = __hip_atomic_load(&queues[laneId * QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const uint64_t live = __ballot(laneId < (uint32_t)TRACE_QUEUES && head < (uint32_t)((uint64_t)(myHi - myLo) * stag / 100u));
+          const uint32_t myLen = queue_len(laneId);
+          const uint64_t live = __ballot(laneId < (uint32_t)TRACE_QUEUES && head < (uint32_t)((uint64_t)myLen * stag / 100u));
           if (live == 0ull) { exhausted = true; break; }
           const uint64_t rot = (live >> qCur) | (qCur ? (live << (64u - qCur)) : 0ull); // bit k = queue (qCur+k)&63
           qCur = (qCur + (uint32_t)__builtin_ctzll(rot)) & (uint32_t)(TRACE_QUEUES - 1);
@@ -196,7 +204,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       if (poolNext != poolEnd) {
         const uint32_t mine = poolNext + lane_rank(idleMask);
         if (!(st & ST_ACTIVE) && mine < poolEnd) {
-          rayIdx = mine;
+          rayIdx = survivors ? survivors[mine] : mine;
           const char* rp = (const char*)P.rays + (size_t)rayIdx * P.stride;
           load_ray<VEC>(rp, r);
           r.hit = 0u;

@@ -5,6 +5,7 @@
 //   epilog / tie rules    kernels/geometry/intersector_epilog.h:226-307 (closest), :388-450 (any hit)
 #include "trace_loop.hip.h"
 #include "trace_pool.hip.h"
+#include "trace_cull.hip.h"
 
 namespace rtamd {
 namespace dev {
@@ -155,6 +156,14 @@ template <bool PLUECKER> struct TriLeaf
 };
 
 } // namespace dev
+
+hipError_t launch_cull(const LaunchParams& p, hipStream_t stream)
+{
+  // every subdivision accel and Triangle4v traverse robustly, Triangle4 with the fast test (same choice as the traversal kernels)
+  const bool robust = p.accel.kind != ACCEL_TRI_MOELLER;
+  if (robust) return p.occluded ? dev::launch_cull_vec<true, true>(p, stream) : dev::launch_cull_vec<true, false>(p, stream);
+  return p.occluded ? dev::launch_cull_vec<false, true>(p, stream) : dev::launch_cull_vec<false, false>(p, stream);
+}
 
 hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream)
 {

@@ -75,7 +75,8 @@ struct RTCAMDTraceCounters
   unsigned long long innerVisits; /* cBVH-internal 4-byte nodes decoded / GridSOA cells tested */
   unsigned long long hits;        /* rays that report a hit */
   unsigned long long stackSpills; /* pushes that overflowed the LDS stack into the HBM spill area */
-  unsigned long long reserved;
+  unsigned long long reserved;    /* rays that survived the root cull pre-pass (0: the pre-pass did not run); `rays` and `nodeVisits`
+                                     include the rays / root visits of the pre-pass */
   /* shader-clock cycles summed over wavefronts, per phase of the traversal loop (the phases are wave-uniform):
      ray fetch, inner-node step, leaf step, pop/finish, and the whole loop.  Diagnostic: where a batch spends time. */
   unsigned long long cyclesFetch, cyclesNode, cyclesLeaf, cyclesPop, cyclesTotal;

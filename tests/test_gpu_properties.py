@@ -118,6 +118,7 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     monkeypatch.setenv("RTAMD_KERNEL", "lane" if kind == "bvh4.compressed.leaf" else "pool")
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
     monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
+    monkeypatch.setenv("RTAMD_CULL", "0")  # no root cull pre-pass: every ray is fetched by the traversal kernel itself
     dev0, sc0 = scene()
     monkeypatch.setenv("RTAMD_KERNEL", "lane")
     ref = rays.clone()
@@ -126,14 +127,19 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     sc0.occluded1M(occ_ref)
     dev0.synchronize()
     hits = int((ref.view(torch.int32)[:, 18] != -1).sum().item())
-    for octmax, octleaf in (("0", "0"), ("8", "1"), ("16", "8"), ("32", "32"), ("16", None)):
+    # (octet node threshold, octet leaf threshold, root cull pre-pass)
+    for octmax, octleaf, cull in (("0", "0", "0"), ("8", "1", "1"), ("16", "8", "0"), ("32", "32", "1"), ("16", None, None)):
         monkeypatch.setenv("RTAMD_OCT_MAX", octmax)
+        if cull is None:
+            monkeypatch.delenv("RTAMD_CULL")  # the library's own default
+        else:
+            monkeypatch.setenv("RTAMD_CULL", cull)
         if octleaf is None:
             monkeypatch.delenv("RTAMD_OCT_LEAF")  # the library's own default
         else:
             monkeypatch.setenv("RTAMD_OCT_LEAF", octleaf)
         dev, sc = scene()
-        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}"
+        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}, cull {cull}"
         for rep in range(2):
             got = rays.clone()
             sc.intersect1M(got)
@@ -143,7 +149,8 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
             cnt = sc.intersect1M_counted(got)
             dev.synchronize()
             assert torch.equal(got, ref), f"{what}, counted twin, run {rep}"
-            assert cnt["hits"] == hits
+            assert cnt["hits"] == hits and cnt["rays"] == n
+            assert (cnt["reserved"] > 0) == (cull == "1")  # survivors of the pre-pass, when it ran (off by default)
             occ = rays[:, :48].contiguous().clone()
             sc.occluded1M(occ)
             dev.synchronize()

@@ -6,7 +6,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     k = r['Kernel_Name']
-    if 'trace_kernel' in k and 'false, false, true>' in k:
+    if ('trace_kernel' in k and 'false, false, true>' in k) or 'cull_kernel' in k:
         agg[k[:100]][r['Counter_Name']].append(float(r['Counter_Value']))
         dur[k[:100]].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 for k, v in agg.items():

@@ -19,7 +19,10 @@ def main():
     rows = [r for r in csv.DictReader(open(f)) if "trace_kernel" in r["Kernel_Name"] or "trace_pool_kernel" in r["Kernel_Name"]]
     name = max(set(r["Kernel_Name"] for r in rows), key=lambda n: sum(1 for r in rows if r["Kernel_Name"] == n))
     ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if r["Kernel_Name"] == name)
-    ev = ev[-steps:]  # bench.py's last pass = the in-flight one; its timed steps are the last `steps` launches
+    # the timed in-flight steps = the `steps` consecutive launches with the smallest span (bench.py also launches this kernel in
+    # its one-stream pass, in warm-ups and in the host-pointer sample, all of which are spread out much further)
+    best = min(range(len(ev) - steps + 1), key=lambda i: max(e for _, e in ev[i:i + steps]) - ev[i][0])
+    ev = ev[best:best + steps]
     t0, t1 = ev[0][0], max(e for _, e in ev)
     dur = sorted(e - s for s, e in ev)
     pts = sorted([(s, 1) for s, _ in ev] + [(e, -1) for _, e in ev])
