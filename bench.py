@@ -39,10 +39,10 @@ IO_BYTES_PER_RAY = 84  # 48 B RTCRay read + 36 B (tfar, Ng, u, v, primID, geomID
 
 # name -> (device config, geometry kind, oracle mode, dominant-kernel tag in rocprof output, description)
 WORKLOADS = {
-    "cbvh.leaf": ("subdiv_accel=bvh4.compressed.leaf", "subdiv", 4, "CbvhLeaf<1, 3>",
+    "cbvh.leaf": ("subdiv_accel=bvh4.compressed.leaf", "subdiv", 4, "CbvhLeaf<1, 3,",
                   "bomberman.ecs: Catmull-Clark subdiv L6, cBVH C3 pizza-box leaves (bvh4.compressed.leaf), 46528 blobs"),
-    "cbvh.box": ("subdiv_accel=bvh4.compressed.box", "subdiv", 3, "CbvhLeaf<0, 3>", "bomberman subdiv L6/C3, cBVH voxel leaves"),
-    "cbvh.grid": ("subdiv_accel=bvh4.compressed.grid", "subdiv", 5, "CbvhLeaf<2, 3>", "bomberman subdiv L6/C3, cBVH + float vertex grid"),
+    "cbvh.box": ("subdiv_accel=bvh4.compressed.box", "subdiv", 3, "CbvhLeaf<0, 3,", "bomberman subdiv L6/C3, cBVH voxel leaves"),
+    "cbvh.grid": ("subdiv_accel=bvh4.compressed.grid", "subdiv", 5, "CbvhLeaf<2, 3,", "bomberman subdiv L6/C3, cBVH + float vertex grid"),
     "eager": ("subdiv_accel=default", "subdiv", 2, "GridCellLeaf", "bomberman subdiv L6, eager 3x3-vertex grid cells (GridSOA semantics)"),
     "tri": ("tri_accel=bvh8.triangle4v", "tri", 0, "TriLeaf<true>", "configs[1]: bomberman.obj as 1454 fan triangles, BVH8 + Triangle4v/Pluecker"),
 }
@@ -191,11 +191,12 @@ def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world, occluded=False):
             dist.barrier()
 
     trace = sc.occluded1M if occluded else sc.intersect1M
+    ctx = getattr(sc, "bench_ctx", None)  # primary rays carry RTC_INTERSECT_CONTEXT_FLAG_COHERENT like viewer_stream_device.cpp:305
 
     def step(s):
         st = streams[s % len(streams)]
         dev.set_stream(st.cuda_stream)
-        trace(bufs[s], check=False)
+        trace(bufs[s], ctx=ctx, check=False)
 
     # every stream (and every per-launch context of the library) is exercised before the clock starts: first use of a
     # HIP stream costs milliseconds.  The extra untimed steps re-trace warm-up batches, never timed ones.
@@ -204,7 +205,7 @@ def run_loop(torch, dist, sc, dev, streams, bufs, K, W, world, occluded=False):
     for s in range(W, 2 * len(streams) if len(streams) > 1 else 0):
         st = streams[s % len(streams)]
         dev.set_stream(st.cuda_stream)
-        trace(bufs[s % max(W, 1)], check=False)
+        trace(bufs[s % max(W, 1)], ctx=ctx, check=False)
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -267,6 +268,7 @@ def main():
         nonlocal m
         dev, sc = build_scene(rtc, local_rank, workload, mesh, levels)
         dev.set_stream(stream.cuda_stream)
+        sc.bench_ctx = rtc.make_context(coherent=True) if args.rays_kind == "primary" else None
         # distinct batches per step and per rank, generated on the host, resident in HBM before timing starts
         nb = 2 * (K + W) + 1 if nfl > 1 else K + W + 1
         if args.rays_kind == "secondary":
@@ -285,7 +287,7 @@ def main():
             bufs = [torch.from_numpy(np.ascontiguousarray(raygen.make_random_rays(m, lo, hi, seed=D.batch_seed(rank, s))[:, :48 if occluded else 80])).to("cuda")
                     for s in range(nb)]
         torch.cuda.synchronize()
-        cnt = (sc.occluded1M_counted if occluded else sc.intersect1M_counted)(bufs[nb - 1])  # extra batch: work counters -> algorithmic bytes per ray
+        cnt = (sc.occluded1M_counted if occluded else sc.intersect1M_counted)(bufs[nb - 1], ctx=sc.bench_ctx)  # extra batch: work counters -> algorithmic bytes per ray
         # pass 1, one stream: the kernel alone, HIP-event time per launch (the roofline figure; agrees with rocprofv3
         # --kernel-trace of `bench.py --inflight 1`)
         elapsed1, kernel_ms = run_loop(torch, dist, sc, dev, streams[:1], bufs, K, W, world, occluded)

@@ -73,7 +73,9 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_REFILL_BATCH")) tuneRefillBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_LEAF")) tuneOctLeaf = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_CULL")) tuneCull = (uint32_t)std::max(0, atoi(env));
+  if (const char* env = getenv("RTAMD_CBVH_FORM")) tuneCbvhForm = strcmp(env, "quad") == 0 ? 0u : (strcmp(env, "lane") == 0 ? 1u : 2u);
   if (const char* env = getenv("RTAMD_OCT_STEPS")) tuneOctSteps = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_BUSY_BLOCKS")) tuneBusyBlocksOct = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_ALONE_BLOCKS")) tuneAloneBlocksOct = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_MAX")) tuneOctMax = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_KERNEL")) tunePoolKernel = strcmp(env, "pool") == 0 ? 1u : (strcmp(env, "lane") == 0 ? 0u : 2u);

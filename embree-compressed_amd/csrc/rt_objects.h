@@ -117,6 +117,7 @@ struct Device : RefCounted
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH
   uint32_t tuneOctLeaf = 0xFFFFFFFFu; // auto: 16 for triangle leaves, 24 for grid cells (measured optima);    // env RTAMD_OCT_LEAF (trace_loop.hip.h, octet leaf step; leaves that have one)
   uint32_t tuneOctSteps = 2;    // env RTAMD_OCT_STEPS
+  uint32_t tuneCbvhForm = 2;    // env RTAMD_CBVH_FORM: 0 quad form, 1 one ray per lane, 2 by the context's coherent flag (rt_trace.cpp)
   // env RTAMD_CULL=1: root cull pre-pass in front of the lane kernel (trace_cull.hip.h).  OFF by default: measured on MI355X
   // (profiles/r02_cull_ab.txt) it removes 17 % of the wave instructions of a 1 M-ray batch (40.8 M -> 6.0 M + 27.8 M) but the
   // traversal kernel, fed with survivors only, takes longer (158 -> 24 + 181 us alone) and four batches in flight gain nothing
@@ -125,6 +126,7 @@ struct Device : RefCounted
   uint32_t tuneCull = 0;
   uint32_t tuneCullMinRays = 65536; // batches below this size go straight to the traversal kernel (the extra launch costs ~5 us)
   uint32_t tuneAloneBlocksOct = 4; // env RTAMD_ALONE_BLOCKS: workgroups per CU of a batch alone on the chip, octet-only leaf kernels
+  uint32_t tuneBusyBlocksOct = 2;  // env RTAMD_BUSY_BLOCKS: the same with two or more batches running on other streams
   uint32_t tuneOctMax = 16;     // env RTAMD_OCT_MAX (trace_loop.hip.h, octet node step), clamped to the build's TRACE_OCT_MAX in the kernel
   // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU).  Measured on MI355X, 1 M-ray batches:
   // alone on the chip every setting within chunk 128-256, leaf batch 24-40, 2-3 workgroups per CU is within +-4 %; with

@@ -31,7 +31,8 @@ static bool is_device_pointer(const void* p) { return pointer_device(p) >= 0; }
 // cullCountsOut (counted batches): host buffer of TRACE_QUEUES * TRACE_QUEUE_STRIDE words that receives the launch's queue words
 // after the kernels (word 1 of a queue = rays that survived the root cull pre-pass, word 2 = valid rays the pre-pass tested)
 static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
-                      WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr, uint32_t* cullCountsOut = nullptr)
+                      WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr, uint32_t* cullCountsOut = nullptr,
+                      bool coherent = false)
 {
   Device* dev = s->device;
   Device::GpuShard& sh = *dev->shards[si];
@@ -59,13 +60,18 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   }
   p.counters = dCounters;
   p.cbvhLevels = s->compressionLevel;
+  // coherent batches (RTC_INTERSECT_CONTEXT_FLAG_COHERENT, e.g. the primary rays of viewer_stream_device.cpp:305) keep most lanes at
+  // blobs at once: one ray per lane; everything else: quad form.  RTAMD_CBVH_FORM=quad|lane overrides.
+  p.cbvhLaneForm = dev->tuneCbvhForm == 2u ? (coherent ? 1u : 0u) : dev->tuneCbvhForm;
   p.numCUs = (uint32_t)sh.numCUs;
   p.rayChunk = dev->tuneChunk;
   p.leafBatch = dev->tuneLeafBatch;
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;
   p.octSteps = dev->tuneOctSteps;
-  p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : ((A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER) ? 16u : 24u);
+  // waiting rays from which the child-parallel leaf phase runs: triangle leaves 16, grid cells 24 (measured optima), cBVH blobs
+  // (quad form, 16 rays per pass) 16
+  p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : (A.kind == ACCEL_GRIDSOA ? 24u : 16u);
   p.exclOffsets = exclOffsets;
   p.exclPairs = exclPairs;
   p.overflow = sh.overflowDev;
@@ -81,10 +87,11 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
   // (The grid-cell kernel, whose leaves are always tested 8 lanes per ray, needs 118 VGPRs: four waves per SIMD fit, and a batch
   // alone on the chip is 10 % faster with four workgroups per CU; 0.169 -> 0.151 ms.)
-  const uint32_t aloneBlocks = A.kind == ACCEL_GRIDSOA ? dev->tuneAloneBlocksOct : 2u;
+  const bool octOnly = A.kind == ACCEL_GRIDSOA || A.kind == ACCEL_CBVH_BOX || A.kind == ACCEL_CBVH_LEAF || A.kind == ACCEL_CBVH_GRID; // four waves per SIMD
+  const uint32_t aloneBlocks = octOnly ? dev->tuneAloneBlocksOct : 2u;
   // with that fourth wave slot two workgroups per CU per batch are also the better grid in flight (eager, 40 steps: random rays
   // 13.3 -> 13.8 Grays/s, shadow rays 9.3 -> 9.8, camera rays 7.1 -> 7.7)
-  const uint32_t busyBlocks = A.kind == ACCEL_GRIDSOA ? 2u : 1u;
+  const uint32_t busyBlocks = octOnly ? dev->tuneBusyBlocksOct : 1u;
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? busyBlocks : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
   p.queues = (uint32_t*)ctx.queues;
   // Root cull pre-pass (trace_cull.hip.h): large batches on the lane kernel whose root is an inner node.  Filter re-traces
@@ -269,6 +276,7 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
     return;
   }
   const uint32_t instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
+  const bool coherent = ctx && (ctx->flags & RTC_INTERSECT_CONTEXT_FLAG_COHERENT);
   const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
 
   // instrumented twin: every wavefront stores one WaveRecord; first half of the log = triangle launch, second = subdiv.
@@ -303,8 +311,8 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
       dCounters2 = dCounters + WAVE_LOG_CAPACITY;
       HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
     }
-    launch_on(s, s->triAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters, nullptr, nullptr, cull1);
-    launch_on(s, s->subdivAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2, nullptr, nullptr, cull2);
+    launch_on(s, s->triAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters, nullptr, nullptr, cull1, coherent);
+    launch_on(s, s->subdivAccel, si, rays, M, (uint32_t)byteStride, occluded, instID, dCounters2, nullptr, nullptr, cull2, coherent);
   } else {
     // Host records: staged through pinned memory.  With several shards the M rays are split into contiguous ranges
     // [g*M/G, (g+1)*M/G), one per shard: H2D, traversal and D2H of the ranges run concurrently on the shards' own streams
@@ -332,8 +340,8 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
         dCounters2 = dCounters + WAVE_LOG_CAPACITY;
         HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
       }
-      launch_on(s, s->triAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters, nullptr, nullptr, cull1);
-      launch_on(s, s->subdivAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters2, nullptr, nullptr, cull2);
+      launch_on(s, s->triAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters, nullptr, nullptr, cull1, coherent);
+      launch_on(s, s->subdivAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters2, nullptr, nullptr, cull2, coherent);
       HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
     }
     for (size_t g = 0; g < G; g++) {

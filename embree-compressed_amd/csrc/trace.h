@@ -18,6 +18,7 @@ struct LaunchParams
   uint32_t spillDepth; // entries per lane available in `spill`
   uint32_t gridBlocks; // persistent grid size the spill area was sized for
   uint32_t cbvhLevels; // fork: depth C of every cBVH blob of the scene (rtcSetSceneLevels)
+  uint32_t cbvhLaneForm; // fork, lane kernel: 1 = walk blobs one ray per lane (coherent batches), 0 = quad form (trace_subdiv.hip)
   WaveRecord* counters;    // non-null selects the instrumented kernel twin; one record per wavefront
   uint32_t numCUs;         // compute units of the device (persistent grid sizing)
   uint32_t rayChunk;       // rays per work-queue grab (tuning knob, env RTAMD_CHUNK)

@@ -63,7 +63,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) // number of set bi
 // change; what changes is the critical path of the few deep rays that bound a batch's drain (measured on MI355X: a lone
 // ray needs ~1.1 us per lane-per-ray node step) and the instructions those nearly empty waves take from everybody else.
 #ifndef TRACE_OCT_MAX
-#define TRACE_OCT_MAX 32
+#define TRACE_OCT_MAX 30 // exchange rows per wave: 4 waves x 30 rows x 48 B + 17 stack rows + the cBVH tables keep a workgroup at 40 704 B of LDS, four per CU
 #endif
 static constexpr int OCT_ROWS = TRACE_OCT_MAX > 0 ? TRACE_OCT_MAX : 1; // rays per wave the exchange area holds
 static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner thread + ray.tfar
@@ -527,8 +527,10 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          for (uint32_t base = 0; base < nRows; base += 8u) {
-            const uint32_t row = base + (lid >> 3);
+          // Leaf::GROUP lanes per ray: 8 (a block pair of triangles, the 8 triangles of a grid cell) or 4 (the quadtree of a cBVH blob)
+          constexpr uint32_t GROUP = (uint32_t)Leaf::GROUP;
+          for (uint32_t base = 0; base < nRows; base += 64u / GROUP) {
+            const uint32_t row = base + lid / GROUP;
             Leaf::template octet_pass<OCCLUDED, COUNT>(P, octX[min(row, nRows - 1u)], row < nRows, lid, wc);
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -540,6 +542,17 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
               if (OCCLUDED) {
                 r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201
                 sp = 0;           // any hit found: terminate this ray
+              } else if constexpr (Leaf::HIT_IN_MEMORY) {
+                // the hit goes to the ray record now (a later, nearer hit overwrites it; nothing is stored when the ray ends): five
+                // registers less across the loop for kernels at a register limit.  The ray's tfar in memory shrinks as it goes.
+                RayState hr;
+                hr.tfar = x[0]; hr.u = x[4]; hr.v = x[5];
+                hr.geomID = __float_as_uint(x[6]); hr.primID = __float_as_uint(x[7]);
+                float one = 1.f, zero = 0.f;
+                asm volatile("" : "+v"(one), "+v"(zero));
+                hr.ngx = one; hr.ngy = zero; hr.ngz = zero;
+                store_hit<VEC>((char*)P.rays + (size_t)rayIdx * P.stride, hr, P.instID);
+                r.tfar = hr.tfar;
               } else {
                 r.tfar = x[0]; r.ngx = x[1]; r.ngy = x[2]; r.ngz = x[3]; r.u = x[4]; r.v = x[5];
                 r.geomID = __float_as_uint(x[6]); r.primID = __float_as_uint(x[7]);
@@ -589,7 +602,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           char* rp = (char*)P.rays + (size_t)rayIdx * P.stride;
           if (COUNT) wc.hits++;
           if (OCCLUDED) ((float*)rp)[8] = r.tfar;
-          else {
+          else if constexpr (Leaf::HIT_IN_MEMORY) {
+            // already stored when it was found
+          } else {
             // leaves that report a constant normal (the fork's dummy Ng = (1,0,0), compressed.h:575,638) do not keep it in
             // registers across the loop: three VGPRs less in the kernels that sit at the register limit
             if constexpr (Leaf::CONST_NG) {

@@ -72,6 +72,8 @@ struct GridCellLeaf
 {
   static constexpr bool OCTET = true;
   static constexpr bool OCTET_ONLY = true; // lane kernel: cells are always tested 8 lanes per ray (intersect() below serves the ray-pool kernel)
+  static constexpr int GROUP = 8;
+  static constexpr bool HIT_IN_MEMORY = false;
   static constexpr bool CONST_NG = false;
   static constexpr int MIN_WAVES = TRACE_MIN_WAVES_PER_SIMD;
   static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
@@ -250,6 +252,7 @@ struct CbvhCtx
   float tfar;    // local tfar, shrinks with hits
   float near, zFactor;
   uint32_t special; // 0/1 in a vector register (see RayState::hit)
+  const float* row; // quad form only: the ray's exchange row (org at words 0..2), so that the origin need not stay in registers
 #ifdef RTAMD_TRACE_RAY
   uint32_t dbgRay; // development aid: -DRTAMD_TRACE_RAY=<index> prints the cell tests of that ray (tools/fork_diff.py)
 #endif
@@ -281,7 +284,7 @@ __device__ __forceinline__ float intersect_line(float p2x, float p2y, float p3x,
 }
 
 // commit a hit found inside the blob (compressed.h:570-591 / :631-653)
-__device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float t)
+template <bool ROW = false> __device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float t)
 {
   RayState& r = *c.r;
   const CbvhHeader* H = c.H;
@@ -297,19 +300,23 @@ __device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float 
     float px, py, pz;
     project3(H->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
     const float* S = H->space; // lOrg again (same fma chain as at blob entry)
-    const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
-    const float loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
-    const float loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
+    const float rox = ROW ? c.row[0] : r.ox, roy = ROW ? c.row[1] : r.oy, roz = ROW ? c.row[2] : r.oz;
+    const float lox = madd(rox, S[0], madd(roy, S[1], roz * S[2]));
+    const float loy = madd(rox, S[3], madd(roy, S[4], roz * S[5]));
+    const float loz = madd(rox, S[6], madd(roy, S[7], roz * S[8]));
     const float ex = px - lox, ey = py - loy, ez = pz - loz;
     r.tfar = sqrtf(madd(ex, ex, madd(ey, ey, ez * ez)));
   } else
     r.tfar = t / c.zFactor + c.near;
 }
 
-// intersect_patch, compressed_help.h:135-229
-__device__ __forceinline__ bool intersect_patch(uint32_t idx, float rcp_edges, float dz, float t1, float t2, float v0, float v1, float v2,
-                                                float v3, float blx, float bly, float bhx, float bhy, const CbvhCtx& c, float& u, float& v,
-                                                float& tt)
+// intersect_patch, compressed_help.h:135-229, split in two: patch_candidate evaluates everything that does not depend on the
+// distance found so far and returns 0 = no hit, 1 = hit at the entry point t1 (cell too small, or entry point inside the slab:
+// accepted whatever tt is), 2 = secant hit at t inside [t1, t2] (accepted iff t < tt); intersect_patch adds that last test.
+// The quad form (below) evaluates the candidates of the four cells of a node in parallel and resolves them in visiting order.
+__device__ __forceinline__ uint32_t patch_candidate(uint32_t idx, float rcp_edges, float dz, float t1, float t2, float v0, float v1, float v2,
+                                                    float v3, float blx, float bly, float bhx, float bhy, const CbvhCtx& c, float& u, float& v,
+                                                    float& t)
 {
   const float px = t1 * c.dx + c.ox, py = t1 * c.dy + c.oy, pz = t1 * c.dz + c.oz;
   const float p2x = t2 * c.dx + c.ox, p2y = t2 * c.dy + c.oy, p2z = t2 * c.dz + c.oz;
@@ -317,10 +324,10 @@ __device__ __forceinline__ bool intersect_patch(uint32_t idx, float rcp_edges, f
   const float fx1 = (px - blx) * lenX, fy1 = (py - bly) * lenY;
   const float mx = (float)compact1by1(idx), my = (float)compact1by1(idx >> 1);
   if (t2 - t1 < 1.0E-6f) { // too small a patch
-    tt = t1;
+    t = t1;
     u = (fx1 + mx) * rcp_edges;
     v = (fy1 + my) * rcp_edges;
-    return true;
+    return 1u;
   }
   const float fx2 = (p2x - blx) * lenX, fy2 = (p2y - bly) * lenY;
   const float dx1 = 1.f - fx1, dy1 = 1.f - fy1;
@@ -328,25 +335,33 @@ __device__ __forceinline__ bool intersect_patch(uint32_t idx, float rcp_edges, f
   const float dx2 = 1.f - fx2, dy2 = 1.f - fy2;
   float z2 = v0 * dx2 * dy2 + v1 * fx2 * dy2 + v2 * dx2 * fy2 + v3 * fx2 * fy2;
   if (pz >= z1 && pz <= z1 + dz) { // entry point inside the slab
-    tt = t1;
+    t = t1;
     u = (fx1 + mx) * rcp_edges;
     v = (fy1 + my) * rcp_edges;
-    return true;
+    return 1u;
   }
   if (pz > z1 + dz) { z1 += dz; z2 += dz; }
   const float alpha = p2z - z2, beta = z1 - pz;
-  const float t = (t1 * alpha + t2 * beta) / (alpha + beta);
-  const float d = (t - t1) / (t2 - t1);
+  const float ts = (t1 * alpha + t2 * beta) / (alpha + beta);
+  const float d = (ts - t1) / (t2 - t1);
   const float fx = fx2 - fx1, fy = fy2 - fy1;
-#ifdef RTAMD_TRACE_RAY
-  if (c.dbgRay == RTAMD_TRACE_RAY)
-    printf("    GPU patch idx %u t1 %a t2 %a | v %a %a %a %a dz %a | box x %a %a y %a %a | org %a %a %a dir %a %a %a | p %a %a %a p2 %a %a %a | len %a %a f1 %a %a f2 %a %a | z1 %a z2 %a alpha %a beta %a t %a d %a tt %a\n",
-           idx, t1, t2, v0, v1, v2, v3, dz, blx, bhx, bly, bhy, c.ox, c.oy, c.oz, c.dx, c.dy, c.dz, px, py, pz, p2x, p2y, p2z, lenX, lenY, fx1, fy1, fx2, fy2, z1, z2, alpha, beta, t, d, tt);
-#endif
-  if (t < tt && t >= t1 && t <= t2) {
+  if (ts >= t1 && ts <= t2) {
     u = (fx * d + fx1 + mx) * rcp_edges;
     v = (fy * d + fy1 + my) * rcp_edges;
-    tt = t;
+    t = ts;
+    return 2u;
+  }
+  return 0u;
+}
+
+__device__ __forceinline__ bool intersect_patch(uint32_t idx, float rcp_edges, float dz, float t1, float t2, float v0, float v1, float v2,
+                                                float v3, float blx, float bly, float bhx, float bhy, const CbvhCtx& c, float& u, float& v,
+                                                float& tt)
+{
+  float t, cu, cv;
+  const uint32_t kind = patch_candidate(idx, rcp_edges, dz, t1, t2, v0, v1, v2, v3, blx, bly, bhx, bhy, c, cu, cv, t);
+  if (kind == 1u || (kind == 2u && t < tt)) {
+    u = cu; v = cv; tt = t;
     return true;
   }
   return false;
@@ -515,14 +530,298 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
   }
 }
 
-template <int MODE, int LEVELS> struct CbvhLeaf
+// ---------------------------------------------------------------------------------------------------
+// fork: cBVH blob, QUAD form (lane kernel): four lanes per ray, lane q of a quad = child q of the current quadtree node
+// ---------------------------------------------------------------------------------------------------
+// The blob walk above keeps one ray per lane: three nested levels of parent boxes, child words and visiting orders in registers
+// (the kernel sat at the 168-VGPR limit of three waves per SIMD) and ~1500 dependent wave instructions per visit, most of them
+// with a handful of lanes active because the rays of a wave are at different depths of different blobs.  In the quad form the
+// four children of a node are decoded and slab-tested by the four lanes of a quad at once, the four frustum edges, the
+// projections of the entry / exit point and the three reciprocals of the local direction go one per lane, the four cells of a
+// last-level node are evaluated in parallel (patch_candidate) and then resolved in visiting order, because a hit shortens the
+// local tfar the later cells see.  Control flow is uniform within a quad; values move between its lanes by DPP (fixed patterns)
+// or ds_bpermute (the child chosen at run time).  Arithmetic, visiting order (nearest first, equal distances -> lower index
+// first, compressed.h:690-749) and every quirk are those of the lane-per-ray form - which the ray-pool kernel still runs, so the
+// two are compared byte for byte by tests/test_gpu_properties.py - hence of the reference.
+enum : int { DPP_Q0 = 0x00, DPP_Q1 = 0x55, DPP_Q2 = 0xAA, DPP_Q3 = 0xFF }; // quad_perm: broadcast lane 0..3 of the quad
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) { return __uint_as_float(dpp_u32<CTRL>(__float_as_uint(v))); }
+// value `v` of lane `src` (0..3, uniform within the quad) of this lane's quad
+__device__ __forceinline__ uint32_t quad_get(uint32_t v, uint32_t src, uint32_t lid)
 {
-  static constexpr bool OCTET = false;
-  static constexpr bool OCTET_ONLY = false;
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lid & ~3u) + src) << 2), (int)v);
+}
+__device__ __forceinline__ float quad_getf(float v, uint32_t src, uint32_t lid) { return __uint_as_float(quad_get(__float_as_uint(v), src, lid)); }
+__device__ __forceinline__ uint32_t quad_ballot(bool p, uint32_t lid) { return (uint32_t)(__ballot(p) >> (lid & 60u)) & 0xFu; }
+
+// Row layout while a quad walks a blob (words of the ray's exchange row): 0..2 ray origin (kept for the flat-frame distance), 3 world
+// distance of the hit so far, 4 `near`, 5 zFactor, 6 `special`, 7 / 8 u / v of the hit so far, 9 hit flag.  The commit-only part of
+// the context and the hit itself live there instead of in seven registers; all four lanes write the same values.
+enum : int { QR_TFAR = 3, QR_NEAR = 4, QR_ZFACTOR = 5, QR_SPECIAL = 6, QR_U = 7, QR_V = 8, QR_HIT = 9 };
+__device__ __forceinline__ void quad_commit(CbvhCtx& c, float u, float v, float t) // cbvh_commit for the leaf / box modes of the quad form
+{
+  const CbvhHeader* H = c.H;
+  float* x = (float*)c.row;
+  x[QR_U] = H->uv0x + u * H->uv1x;
+  x[QR_V] = H->uv0y + v * H->uv1y;
+  x[QR_HIT] = __uint_as_float(1u);
+  c.tfar = t;
+  if (__float_as_uint(x[QR_SPECIAL]) != 0u) {
+    // flat frame: un-project the local hit point and measure the distance in the rotated world frame (:583-587)
+    float px, py, pz;
+    project3(H->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
+    const float* S = H->space; // lOrg again (same fma chain as at blob entry)
+    const float rox = x[0], roy = x[1], roz = x[2];
+    const float lox = madd(rox, S[0], madd(roy, S[1], roz * S[2]));
+    const float loy = madd(rox, S[3], madd(roy, S[4], roz * S[5]));
+    const float loz = madd(rox, S[6], madd(roy, S[7], roz * S[8]));
+    const float ex = px - lox, ey = py - loy, ez = pz - loz;
+    x[QR_TFAR] = sqrtf(madd(ex, ex, madd(ey, ey, ez * ez)));
+  } else
+    x[QR_TFAR] = t / x[QR_ZFACTOR] + x[QR_NEAR];
+}
+
+template <int MODE, int LEVELS, int REM, bool COUNT>
+__device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t curr, uint32_t w, float blx, float bly, float blz, float bhx, float bhy,
+                                          float bhz, WorkCounters& wc)
+{
+  const uint32_t q = lid & 3u;
+  // this lane's child: its node word / its cell's two height bytes, requested before anything else (one 16-byte / 8-byte access per quad)
+  uint32_t cw = 0u;
+  if constexpr (REM > 1) cw = CbvhGeom<LEVELS>::nodes(c.H)[4u * curr + 1u + q];
+  else if constexpr (MODE == MODE_LEAF) cw = ((const uint16_t*)CbvhGeom<LEVELS>::leaves(c.H))[4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS];
+  if (COUNT && q == 0u) wc.inner++;
+  // getNode, compressed_node.h:488-510, the planes of child q only (x column = q & 1, y row = q >> 1)
+  const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
+  const float* T = cbvh_tables();
+  const uint32_t xl = (q & 1u) ? TBL_MID + ((w >> 2) & 7u) : TBL_BORDER + ((w >> 5) & 7u);
+  const uint32_t xu = (q & 1u) ? TBL_ONE_MINUS_BORDER + ((w >> 10) & 7u) : TBL_ONE_MINUS_MID + ((w >> 13) & 7u);
+  const uint32_t yl = (q & 2u) ? TBL_MID + ((w >> 18) & 7u) : TBL_BORDER + ((w >> 21) & 7u);
+  const uint32_t yu = (q & 2u) ? TBL_ONE_MINUS_BORDER + ((w >> 26) & 7u) : TBL_ONE_MINUS_MID + ((w >> 29) & 7u);
+  const float lx = T[xl] * dimX + blx, ux = T[xu] * dimX + blx;
+  const float ly = T[yl] * dimY + bly, uy = T[yu] * dimY + bly;
+  const float lz = (float)(w & 3) * 0.25f * dimZ + blz;
+  const float uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
+  // intersectNodeRobust (node_intersector1.h:351-368) for this child
+  const bool negx = !(c.rnx >= 0.f), negy = !(c.rny >= 0.f), negz = !(c.rnz >= 0.f);
+  const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
+  const float rfx = c.rnx * ulp3, rfy = c.rny * ulp3, rfz = c.rnz * ulp3;
+  const float nX = ((negx ? ux : lx) - c.ox) * c.rnx, fX = ((negx ? lx : ux) - c.ox) * rfx;
+  const float nY = ((negy ? uy : ly) - c.oy) * c.rny, fY = ((negy ? ly : uy) - c.oy) * rfy;
+  const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * rfz;
+  const float tN = fmaxf(fmaxf(nX, nY), fmaxf(nZ, 0.f));
+  const float tF = fminf(fminf(fX, fY), fminf(fZ, c.travFar));
+  const bool h = tN <= tF;
+  const uint32_t nhit = (uint32_t)__popc(quad_ballot(h, lid));
+  if (nhit == 0u) return;
+  // visiting position of this lane's child: children that are nearer, or equally near with a lower index, come first
+  // (compressed.h:690-749); 4 = not hit.  (One register per level across the descent: no lane masks, no separate hit flag.)
+  const uint32_t d = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+  const uint32_t d1 = dpp_u32<DPP_XOR1>(d), d2 = dpp_u32<DPP_XOR2>(d), d3 = dpp_u32<DPP_XOR3>(d);
+  uint32_t pos = 0u;
+  pos += d1 < d + ((q ^ 1u) < q ? 1u : 0u) ? 1u : 0u;
+  pos += d2 < d + ((q ^ 2u) < q ? 1u : 0u) ? 1u : 0u;
+  pos += d3 < d + ((q ^ 3u) < q ? 1u : 0u) ? 1u : 0u;
+  pos = h ? pos : 4u;
+
+  if constexpr (REM > 1) {
+    for (uint32_t k = 0; k < nhit; k++) {
+      const uint32_t src = (uint32_t)__ffs(quad_ballot(pos == k, lid)) - 1u; // the child visited k-th
+      const float cbx0 = quad_getf(lx, src, lid), cbx1 = quad_getf(ux, src, lid);
+      const float cby0 = quad_getf(ly, src, lid), cby1 = quad_getf(uy, src, lid);
+      const uint32_t cword = quad_get(cw, src, lid);
+      quad_node<MODE, LEVELS, REM - 1, COUNT>(c, lid, 4u * curr + 1u + src, cword, cbx0, cby0, lz, cbx1, cby1, uz, wc);
+    }
+  } else if constexpr (MODE == MODE_LEAF) { // compressed.h:539-593
+    // candidates of the (up to) four cells in parallel; none of this depends on the distance found so far
+    float ct = 0.f, cu = 0.f, cv = 0.f;
+    uint32_t kind = 0u;
+    if (pos != 4u) {
+      const float range = (1.f + 2.f * c.H->extent) * (uz - lz);
+      const float dz = 0.0625f * range; // getDelta() = rcp(16) (compressed_leaf.h:109-111)
+      const float rcpF = 0.0625f * range;
+      const float off = lz - (uz - lz) * c.H->extent;
+      const uint32_t z12 = cw & 0xffu, z34 = (cw >> 8) & 0xffu;
+      const float z1 = off + rcpF * (float)(z12 >> 4), z2 = off + rcpF * (float)(z12 & 0xf);
+      const float z3 = off + rcpF * (float)(z34 >> 4), z4 = off + rcpF * (float)(z34 & 0xf);
+      kind = patch_candidate(4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS, c.H->rcp_edges, dz, tN, tF, z1, z2, z3, z4, lx, ly, ux, uy, c, cu, cv, ct);
+    }
+    // resolution in visiting order: a cell is skipped once its box entry lies behind the hit so far (`tN >= tfar`), a secant
+    // hit counts only in front of it (`t < tt`)
+    for (uint32_t k = 0; k < nhit; k++) {
+      const bool tested = pos == k && !(tN >= c.tfar);
+      if (COUNT && tested) wc.inner++;
+      const uint32_t acc = quad_ballot(tested && (kind == 1u || (kind == 2u && ct < c.tfar)), lid);
+      if (acc != 0u) {
+        const uint32_t src = (uint32_t)__ffs(acc) - 1u;
+        quad_commit(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(ct, src, lid));
+      }
+    }
+  } else if constexpr (MODE == MODE_BOX) { // voxel, compressed.h:614-654: the box entry point is the hit
+    float cu = 0.f, cv = 0.f;
+    if (pos != 4u) {
+      const uint32_t idx = 4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS;
+      cu = (((c.ox + c.dx * tN) - lx) / (ux - lx) + (float)compact1by1(idx)) * c.H->rcp_edges;
+      cv = (((c.oy + c.dy * tN) - ly) / (uy - ly) + (float)compact1by1(idx >> 1)) * c.H->rcp_edges;
+    }
+    for (uint32_t k = 0; k < nhit; k++) {
+      const bool take = pos == k && tN <= c.tfar;
+      if (COUNT && take) wc.inner++;
+      const uint32_t acc = quad_ballot(take, lid);
+      if (acc != 0u) {
+        const uint32_t src = (uint32_t)__ffs(acc) - 1u;
+        quad_commit(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(tN, src, lid));
+      }
+    }
+  } else { // MODE_GRID (compressed.h:597-611): true triangles on the world ray, one cell after the other on all four lanes
+    for (uint32_t k = 0; k < nhit; k++) {
+      const uint32_t src = (uint32_t)__ffs(quad_ballot(pos == k, lid)) - 1u;
+      WorkCounters dummy;
+      cbvh_cell<MODE_GRID, LEVELS, COUNT>(c, 4u * curr + 1u + src - CbvhGeom<LEVELS>::ELEMS, 0u, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, q == 0u ? wc : dummy);
+    }
+  }
+}
+
+// QUAD = true: in the lane kernel blobs are walked in the quad form only (four lanes per ray, octet_pass below; 128 VGPRs, four waves
+// per SIMD): the form for incoherent rays, most of which miss - the metric's workload.  QUAD = false: one ray per lane (intersect()
+// below, 168 VGPRs, three waves): the better use of the wave when most lanes wait at blobs at once, i.e. for coherent camera
+// rays (measured round 2, 1920x1080 primary rays: 0.754 ms against 0.975 ms for the quad form; random rays: 0.159 ms against
+// 0.148 ms).  The caller's RTCIntersectContext::flags decide (RTC_INTERSECT_CONTEXT_FLAG_COHERENT -> QUAD = false), as in the
+// reference, where that flag selects the coherent traversal kernels (rtcore.cpp:411-417).  The ray-pool kernel always uses intersect().
+template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
+{
+  static constexpr bool OCTET = QUAD;
+  static constexpr bool OCTET_ONLY = QUAD;
+  static constexpr int GROUP = 4;
   static constexpr bool CONST_NG = true; // dummy normal (1,0,0): written at store time by the lane kernel
-  // four and five quadtree levels keep four / five parent boxes in registers: bounded at 3 waves per SIMD those kernels spill
-  // 60-330 bytes per lane, so they are compiled for 2 waves per SIMD (<= 256 VGPRs) instead
-  static constexpr int MIN_WAVES = LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD;
+  static constexpr bool HIT_IN_MEMORY = QUAD; // quad form: a hit is written to the ray record when it is found; only tfar stays in registers
+  static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
+
+  // Quad form of intersect() below for the ray in exchange row `x` (words 0..7 = org, tnear, dir, tfar; word 8 = leaf ref); lane
+  // q of the quad `lid >> 2`.  On a hit lane 0 of the quad writes tfar, u, v, geomID, primID into words 0, 4..7 and sets word 9.
+  template <bool OCCLUDED, bool COUNT>
+  static __device__ __forceinline__ void octet_pass(const LaunchParams& P, float* x, bool valid, uint32_t lid, WorkCounters& wc)
+  {
+    if (!valid) return; // uniform within the quad
+    const uint32_t q = lid & 3u;
+    RayState r;
+    r.ox = x[0]; r.oy = x[1]; r.oz = x[2]; r.tnear = x[3];
+    r.dx = x[4]; r.dy = x[5]; r.dz = x[6]; r.tfar = x[7];
+    r.hit = 0u;
+    const uint32_t idx = __float_as_uint(x[8]) & 0x7FFFFFFFu;
+    const CbvhHeader* H = (const CbvhHeader*)(P.accel.blobs + (size_t)idx * P.accel.blobStride);
+    if (COUNT && q == 0u) wc.prims++;
+    if (OCCLUDED) { // the fork's occluded() stub (compressed.h:754-756): see intersect() below
+      const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx, zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy, zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
+      const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
+      const float rnx = 1.0f / zx, rny = 1.0f / zy, rnz = 1.0f / zz;
+      const float nx = ((rnx >= 0.f ? H->wlo[0] : H->whi[0]) - r.ox) * rnx, fx = ((rnx >= 0.f ? H->whi[0] : H->wlo[0]) - r.ox) * (rnx * ulp3);
+      const float ny = ((rny >= 0.f ? H->wlo[1] : H->whi[1]) - r.oy) * rny, fy = ((rny >= 0.f ? H->whi[1] : H->wlo[1]) - r.oy) * (rny * ulp3);
+      const float nz = ((rnz >= 0.f ? H->wlo[2] : H->whi[2]) - r.oz) * rnz, fz = ((rnz >= 0.f ? H->whi[2] : H->wlo[2]) - r.oz) * (rnz * ulp3);
+      const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, fmaxf(r.tnear, 0.f)));
+      const float tf = fminf(fminf(fx, fy), fminf(fz, fmaxf(r.tfar, 0.f)));
+      if (q == 0u && tn <= tf) x[9] = __uint_as_float(1u);
+      return;
+    }
+    CbvhCtx c;
+    c.H = H;
+    c.r = &r;
+    c.row = x;
+    const uint32_t rootWord = CbvhGeom<LEVELS>::nodes(H)[0];
+    // rotate the ray into the local frame (:458-459), on all four lanes
+    const float* S = H->space;
+    const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
+    const float loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
+    const float loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
+    const float ldx = madd(r.dx, S[0], madd(r.dy, S[1], r.dz * S[2]));
+    const float ldy = madd(r.dx, S[3], madd(r.dy, S[4], r.dz * S[5]));
+    const float ldz = madd(r.dx, S[6], madd(r.dy, S[7], r.dz * S[8]));
+    // intersect_frustum (compressed_help.h:109-133): edge q on lane q (t1x: corners 1-3, t2x: 2-4, t1y: 1-2, t2y: 3-4; corner j at
+    // box[2j], box[2j+1]), then every lane combines the four values in the reference's order
+    float near = r.tnear, far = r.tfar;
+    {
+      const float* B = H->box;
+      const uint32_t a = 2u + ((0x4020u >> (4u * q)) & 15u), b = 2u + ((0x6264u >> (4u * q)) & 15u); // start / end corner of edge q
+      const float tq = intersect_line(B[a], B[a + 1u], B[b], B[b + 1u], lox, loy, ldx, ldy);
+      const float t1x = dpp_f32<DPP_Q0>(tq), t2x = dpp_f32<DPP_Q1>(tq), t1y = dpp_f32<DPP_Q2>(tq), t2y = dpp_f32<DPP_Q3>(tq);
+      const float rz = 1.0f / (fabsf(ldz) < 1e-18f ? 1e-18f : ldz); // rcp_safe
+      const float orz = loz * rz;
+      const float t1z = B[0] * rz - orz, t2z = B[1] * rz - orz;
+      const float near1 = fminf(fminf(t1x, t2x), fminf(t1y, t2y));
+      const float far1 = fmaxf(fmaxf(t1x, t2x), fmaxf(t1y, t2y));
+      near = fmaxf(fmaxf(fminf(t1z, t2z), near1), near);
+      far = fminf(fminf(fmaxf(t1z, t2z), far1), far);
+      if (!(near <= far && near1 == near1 && far1 == far1)) return;
+    }
+    c.near = near;
+    // projected ray between entry and exit point (:470-508): lane 0 / 1 = x / y of the entry point, lane 2 / 3 = of the exit point
+    float tx, ty, tz;
+    {
+      const float tp = (q & 2u) ? far : near;
+      const float X = lox + ldx * tp, Y = loy + ldy * tp;
+      const float* m = H->proj;
+      const uint32_t row = 3u * (q & 1u);
+      const float pn = (m[row] * X + m[row + 1u] * Y) + m[row + 2u];
+      const float pw = (m[6] * X + m[7] * Y) + m[8];
+      const float pq = pn / pw;
+      c.ox = dpp_f32<DPP_Q0>(pq); c.oy = dpp_f32<DPP_Q1>(pq); tx = dpp_f32<DPP_Q2>(pq); ty = dpp_f32<DPP_Q3>(pq);
+      c.oz = loz + ldz * near;
+      tz = loz + ldz * far;
+    }
+    c.dx = tx - c.ox; c.dy = ty - c.oy; c.dz = tz - c.oz;
+    c.special = 0u;
+    c.zFactor = 0.f;
+    const float g_epsilon = 1.0E-4f;
+    if (fabsf(c.dx) < g_epsilon && fabsf(c.dy) < g_epsilon && fabsf(c.dz) < g_epsilon) {
+      c.dz = copysignf(1.f, ldz);
+      c.oz -= c.dz;
+      c.zFactor = 3.402823466e+38f;
+      c.tfar = 3.402823466e+38f;
+    } else if (fabsf(c.dz) < g_epsilon) {
+      c.special = 1u;
+      const float len2 = madd(c.dx, c.dx, madd(c.dy, c.dy, c.dz * c.dz));
+      c.tfar = sqrtf(len2);
+      const float rl = 1.0f / sqrtf(len2); // reference: rsqrt + Newton step
+      c.dx *= rl; c.dy *= rl; c.dz *= rl;
+    } else {
+      const float len2 = madd(c.dx, c.dx, madd(c.dy, c.dy, c.dz * c.dz));
+      const float rl = 1.0f / sqrtf(len2);
+      c.dx *= rl; c.dy *= rl; c.dz *= rl;
+      c.zFactor = ldz / c.dz;
+      c.tfar = (r.tfar - near) * c.zFactor;
+    }
+    c.travFar = c.tfar;
+    { // rdir_near of the local ray: one reciprocal per lane
+      const float dq = q == 0u ? c.dx : (q == 1u ? c.dy : c.dz);
+      const float rq = 1.0f / (fabsf(dq) < 1e-18f ? 1e-18f : dq);
+      c.rnx = dpp_f32<DPP_Q0>(rq); c.rny = dpp_f32<DPP_Q1>(rq); c.rnz = dpp_f32<DPP_Q2>(rq);
+    }
+    if constexpr (MODE != MODE_GRID) {
+      // what only a commit needs moves into the row (see quad_commit); every lane of the quad writes the same values
+      x[QR_NEAR] = c.near; x[QR_ZFACTOR] = c.zFactor; x[QR_SPECIAL] = __uint_as_float(c.special);
+    }
+    // root: local frame box xy in [-1,1], z from the leaf data (:517-519)
+    quad_node<MODE, LEVELS, LEVELS, COUNT>(c, lid, 0u, rootWord, -1.f, -1.f, H->box[0], 1.f, 1.f, H->box[1], wc);
+    if constexpr (MODE != MODE_GRID) {
+      if (q == 0u && __float_as_uint(x[QR_HIT]) != 0u) { // results into the words the kernel skeleton reads (ids from the header)
+        const float t = x[QR_TFAR], u = x[QR_U], v = x[QR_V];
+        x[0] = t; x[4] = u; x[5] = v;
+        x[6] = __uint_as_float(H->geomID); x[7] = __uint_as_float(H->primID);
+      }
+    } else if (q == 0u && r.hit) {
+      x[0] = r.tfar; x[4] = r.u; x[5] = r.v;
+      x[6] = __uint_as_float(H->geomID); x[7] = __uint_as_float(H->primID);
+      x[9] = __uint_as_float(1u);
+    }
+  }
+
+  // quad form: ~10 VGPRs per quadtree level (119 / 130 / 142 / 152 / 162 for C = 1..5 when bounded at three waves per SIMD);
+  // up to three levels are compiled for FOUR waves per SIMD (<= 128 VGPRs)
+#ifndef TRACE_CBVH_MIN_WAVES
+#define TRACE_CBVH_MIN_WAVES(levels) ((levels) <= 3 ? 4 : TRACE_MIN_WAVES_PER_SIMD)
+#endif
+  // (grid mode walks with the world ray and its hit in registers - its triangle tests feed each other through ray.tfar - and stays at three;
+  // the lane-per-ray form keeps every level's parent box in registers: three waves up to C = 3, two beyond)
+  static constexpr int MIN_WAVES = !QUAD ? (LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD) : (MODE == MODE_GRID ? (LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD) : TRACE_CBVH_MIN_WAVES(LEVELS));
   static __device__ __forceinline__ void prepare() { cbvh_tables_init(); }
 
   template <bool OCCLUDED, bool COUNT>
@@ -625,19 +924,27 @@ template <int MODE, int LEVELS> struct CbvhLeaf
 template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t stream, uint32_t levels)
 {
   if (p.poolKernel) switch (levels) {
-    case 1: return launch_leaf_pool<CbvhLeaf<MODE, 1>, true>(p, stream);
-    case 2: return launch_leaf_pool<CbvhLeaf<MODE, 2>, true>(p, stream);
-    case 3: return launch_leaf_pool<CbvhLeaf<MODE, 3>, true>(p, stream);
-    case 4: return launch_leaf_pool<CbvhLeaf<MODE, 4>, true>(p, stream);
-    case 5: return launch_leaf_pool<CbvhLeaf<MODE, 5>, true>(p, stream);
+    case 1: return launch_leaf_pool<CbvhLeaf<MODE, 1, false>, true>(p, stream);
+    case 2: return launch_leaf_pool<CbvhLeaf<MODE, 2, false>, true>(p, stream);
+    case 3: return launch_leaf_pool<CbvhLeaf<MODE, 3, false>, true>(p, stream);
+    case 4: return launch_leaf_pool<CbvhLeaf<MODE, 4, false>, true>(p, stream);
+    case 5: return launch_leaf_pool<CbvhLeaf<MODE, 5, false>, true>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+  if (p.cbvhLaneForm) switch (levels) { // coherent batches: one ray per lane
+    case 1: return launch_leaf<CbvhLeaf<MODE, 1, false>, true>(p, stream);
+    case 2: return launch_leaf<CbvhLeaf<MODE, 2, false>, true>(p, stream);
+    case 3: return launch_leaf<CbvhLeaf<MODE, 3, false>, true>(p, stream);
+    case 4: return launch_leaf<CbvhLeaf<MODE, 4, false>, true>(p, stream);
+    case 5: return launch_leaf<CbvhLeaf<MODE, 5, false>, true>(p, stream);
     default: return hipErrorInvalidValue;
     }
   switch (levels) {
-  case 1: return launch_leaf<CbvhLeaf<MODE, 1>, true>(p, stream);
-  case 2: return launch_leaf<CbvhLeaf<MODE, 2>, true>(p, stream);
-  case 3: return launch_leaf<CbvhLeaf<MODE, 3>, true>(p, stream);
-  case 4: return launch_leaf<CbvhLeaf<MODE, 4>, true>(p, stream);
-  case 5: return launch_leaf<CbvhLeaf<MODE, 5>, true>(p, stream);
+  case 1: return launch_leaf<CbvhLeaf<MODE, 1, true>, true>(p, stream);
+  case 2: return launch_leaf<CbvhLeaf<MODE, 2, true>, true>(p, stream);
+  case 3: return launch_leaf<CbvhLeaf<MODE, 3, true>, true>(p, stream);
+  case 4: return launch_leaf<CbvhLeaf<MODE, 4, true>, true>(p, stream);
+  case 5: return launch_leaf<CbvhLeaf<MODE, 5, true>, true>(p, stream);
   default: return hipErrorInvalidValue;
   }
 }

@@ -19,6 +19,8 @@ template <bool PLUECKER> struct TriLeaf
 {
   static constexpr bool OCTET = true;
   static constexpr bool CONST_NG = false;
+  static constexpr int GROUP = 8;
+  static constexpr bool HIT_IN_MEMORY = false;
   // Both forms stay in the lane kernel.  Measured with the lane-per-ray form dropped (127 VGPRs, four waves per SIMD): random
   // rays 18.0 -> 19.2 Grays/s in flight, 0.098 -> 0.089 ms alone, but rays that visit many full leaves lose: camera rays 11.4 ->
   // 10.8, bounce rays 10.3 -> 9.4, shadow rays 15.9 -> 13.2 Grays/s (8 lanes per ray test a 4-triangle leaf at half occupancy;

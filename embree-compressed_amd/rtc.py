@@ -201,9 +201,15 @@ class RTCError(RuntimeError):
         self.code = code
 
 
-def make_context(inst_id=RTC_INVALID_GEOMETRY_ID):
+RTC_INTERSECT_CONTEXT_FLAG_INCOHERENT = 0
+RTC_INTERSECT_CONTEXT_FLAG_COHERENT = 1
+
+
+def make_context(inst_id=RTC_INVALID_GEOMETRY_ID, coherent=False):
+    """coherent=True: RTC_INTERSECT_CONTEXT_FLAG_COHERENT, the hint the reference's viewer_stream sets for primary rays; on
+    subdiv_accel=bvh4.compressed.* it selects the one-ray-per-lane blob walk instead of the quad form."""
     ctx = RTCIntersectContext()
-    ctx.flags = 0
+    ctx.flags = RTC_INTERSECT_CONTEXT_FLAG_COHERENT if coherent else RTC_INTERSECT_CONTEXT_FLAG_INCOHERENT
     ctx.filter = None
     ctx.instID[0] = inst_id
     return ctx

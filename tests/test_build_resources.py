@@ -23,7 +23,7 @@ def test_no_scratch_in_the_plain_traversal_kernels():
     # (the C = 3 cBVH walks sit at the 168-VGPR limit of three waves per SIMD: the allocator parks one or two cold tuples - e.g. values
     # that are live across a blob visit but not used in it - in at most 32 bytes; test_metric_kernel_register_budget bounds the
     # number of scratch instructions)
-    allowed = {f"trace_kernel<CbvhLeaf<{m}, 3>, true, false, false, {v}>": 32 for m in (0, 1, 2) for v in ("true", "false")}
+    allowed = {f"trace_kernel<CbvhLeaf<{m}, 3, {f}>, true, false, false, {v}>": 32 for m in (0, 1, 2) for v in ("true", "false") for f in ("true", "false")}
     bad = []
     for n, r in plain.items():
         args = [a.strip() for a in n[n.index("<") + 1 : n.rindex(">")].rsplit(",", 4)]
@@ -36,11 +36,15 @@ def test_no_scratch_in_the_plain_traversal_kernels():
 
 
 def test_metric_kernel_register_budget():
-    metric = "trace_kernel<CbvhLeaf<1, 3>, true, false, false, true>"
-    md = kernel_metadata(LIB, disassemble=(metric,))
-    # BASELINE.json metric path: cbvh.leaf, C = 3, closest hit, 16-byte aligned records: three waves per SIMD, and no spill
-    # traffic worth the name (at most a cold tuple stored before / reloaded after a blob visit: <= 4 scratch instructions)
+    metric = "trace_kernel<CbvhLeaf<1, 3, true>, true, false, false, true>"
+    lane = "trace_kernel<CbvhLeaf<1, 3, false>, true, false, false, true>"
+    md = kernel_metadata(LIB, disassemble=(metric, lane))
+    # BASELINE.json metric path: cbvh.leaf, C = 3, closest hit, 16-byte aligned records, incoherent rays -> quad form:
+    # FOUR waves per SIMD (<= 128 VGPRs, no scratch) and four workgroups per CU (LDS)
     r = md[metric]
+    assert r["scratch"] == 0 and r["vgpr"] <= 128 and 4 * r["lds"] <= 160 * 1024, r
+    # the one-ray-per-lane form (coherent batches): three waves per SIMD, at most a cold tuple in scratch
+    r = md[lane]
     assert r["scratch"] <= 32 and r["vgpr"] <= 168 and r["scratch_ops"] <= 4, r
     g = md["trace_kernel<GridCellLeaf, true, false, false, true>"]
     assert g["scratch"] == 0 and g["vgpr"] <= 128, g  # eager path: four waves per SIMD

@@ -119,6 +119,7 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
     monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
     monkeypatch.setenv("RTAMD_CULL", "0")  # no root cull pre-pass: every ray is fetched by the traversal kernel itself
+    monkeypatch.setenv("RTAMD_CBVH_FORM", "lane")  # cBVH blobs walked one ray per lane (the form the oracle-pinned round-1 kernels had)
     dev0, sc0 = scene()
     monkeypatch.setenv("RTAMD_KERNEL", "lane")
     ref = rays.clone()
@@ -127,9 +128,13 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     sc0.occluded1M(occ_ref)
     dev0.synchronize()
     hits = int((ref.view(torch.int32)[:, 18] != -1).sum().item())
-    # (octet node threshold, octet leaf threshold, root cull pre-pass)
-    for octmax, octleaf, cull in (("0", "0", "0"), ("8", "1", "1"), ("16", "8", "0"), ("32", "32", "1"), ("16", None, None)):
+    # (octet node threshold, octet / quad leaf threshold, root cull pre-pass, cBVH blob walk: one ray per lane / four lanes per ray)
+    for octmax, octleaf, cull, form in (("0", "0", "0", "lane"), ("8", "1", "1", "quad"), ("16", "8", "0", "quad"), ("32", "32", "1", "lane"), ("16", None, None, None)):
         monkeypatch.setenv("RTAMD_OCT_MAX", octmax)
+        if form is None:
+            monkeypatch.delenv("RTAMD_CBVH_FORM")  # the library's own default: by the context's coherent flag (here: quad form)
+        else:
+            monkeypatch.setenv("RTAMD_CBVH_FORM", form)
         if cull is None:
             monkeypatch.delenv("RTAMD_CULL")  # the library's own default
         else:
@@ -139,7 +144,7 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
         else:
             monkeypatch.setenv("RTAMD_OCT_LEAF", octleaf)
         dev, sc = scene()
-        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}, cull {cull}"
+        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}, cull {cull}, cBVH form {form}"
         for rep in range(2):
             got = rays.clone()
             sc.intersect1M(got)
