@@ -43,6 +43,7 @@ WORKLOADS = {
                   "bomberman.ecs: Catmull-Clark subdiv L6, cBVH C3 pizza-box leaves (bvh4.compressed.leaf), 46528 blobs"),
     "cbvh.box": ("subdiv_accel=bvh4.compressed.box", "subdiv", 3, "CbvhLeaf<0, 3,", "bomberman subdiv L6/C3, cBVH voxel leaves"),
     "cbvh.grid": ("subdiv_accel=bvh4.compressed.grid", "subdiv", 5, "CbvhLeaf<2, 3,", "bomberman subdiv L6/C3, cBVH + float vertex grid"),
+    "cbvh.full": ("subdiv_accel=bvh4.compressed.full", "subdiv", 6, "CbvhLeaf<3, 3,", "bomberman subdiv L6/C3, cBVH with float (uncompressed) quadtree nodes, voxel hits"),
     "eager": ("subdiv_accel=default", "subdiv", 2, "GridCellLeaf", "bomberman subdiv L6, eager 3x3-vertex grid cells (GridSOA semantics)"),
     "tri": ("tri_accel=bvh8.triangle4v", "tri", 0, "TriLeaf<true>", "configs[1]: bomberman.obj as 1454 fan triangles, BVH8 + Triangle4v/Pluecker"),
 }
@@ -142,7 +143,7 @@ def cpu_baseline(sc, rtc, workload, mesh, levels, lo, hi, m, budget_s):
     orc.free()
     # true-reference rates measured by the survey (the reference library built there, AVX2, 1 thread,
     # Xeon 2.1 GHz, same scene and ray generator)
-    ref_1t = {"cbvh.leaf": 5.6, "cbvh.box": 7.0, "cbvh.grid": 7.5, "eager": 10.1, "tri": 30.4}.get(workload)
+    ref_1t = {"cbvh.leaf": 5.6, "cbvh.box": 7.0, "cbvh.grid": 7.5, "cbvh.full": 6.1, "eager": 10.1, "tri": 30.4}.get(workload)
     return {"value": total / spent / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x {m} rays of the same generator (seed 12345), {what} (oracle/liboracle.so), {cores} pthreads, blocks of 1024",
             "per_thread_Mrays": per_thread,

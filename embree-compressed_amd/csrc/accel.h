@@ -98,6 +98,10 @@ struct alignas(16) CbvhHeader
   float pad1;
 };
 static const uint32_t CBVH_HEADER_BYTES = 224;
+// bvh4.compressed.full: a quadtree node holds its four child boxes as floats (the reference's NodeStorage<flavor::ref,32,32,32>,
+// compressed_node.h:371-389, 24 floats); here plane-major so that a quad reads one plane of its four children with one access:
+// lx[4], ux[4], ly[4], uy[4], lz[4], uz[4]
+static const uint32_t CBVH_FULL_NODE_BYTES = 96;
 static_assert(sizeof(CbvhHeader) == CBVH_HEADER_BYTES, "CbvhHeader must be 224 bytes");
 
 enum AccelKind : uint32_t
@@ -108,7 +112,8 @@ enum AccelKind : uint32_t
   ACCEL_CBVH_BOX = 3,     // subdiv_accel=bvh4.compressed.box
   ACCEL_CBVH_LEAF = 4,    // subdiv_accel=bvh4.compressed.leaf
   ACCEL_CBVH_GRID = 5,    // subdiv_accel=bvh4.compressed.grid
-  ACCEL_GRIDSOA = 6       // eager subdiv (default subdiv accel)
+  ACCEL_GRIDSOA = 6,      // eager subdiv (default subdiv accel)
+  ACCEL_CBVH_FULL = 7     // subdiv_accel=bvh4.compressed.full: the fork's box mode over UNcompressed quadtree nodes (compressed.h:40,774)
 };
 
 // What a kernel launch needs to know about one committed scene.

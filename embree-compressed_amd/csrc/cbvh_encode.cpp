@@ -304,7 +304,7 @@ size_t cbvh_blob_bytes(unsigned C, CbvhMode mode)
   const size_t cells = (size_t)1 << (2 * C);
   const size_t elems = (cells - 1) / 3;
   const size_t w = ((size_t)1 << C) + 1;
-  size_t n = CBVH_HEADER_BYTES + elems * 4;
+  size_t n = CBVH_HEADER_BYTES + elems * (mode == CBVH_FULL ? (size_t)CBVH_FULL_NODE_BYTES : 4);
   if (mode == CBVH_LEAF) n += cells * 2;
   if (mode == CBVH_GRID) n = ((n + 3) & ~(size_t)3) + w * w * 12;
   return (n + 15) & ~(size_t)15;
@@ -423,9 +423,18 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
   unsigned curr = 0;
   for (unsigned l = 0; l < C; l++)
     for (size_t k = 0; k < hier[l].size(); k++) {
-      cbvh_encode_node(hier[l][k], &hier[l + 1][4 * k], nodes[curr]);
+      if (mode == CBVH_FULL) { // Node<flavor::ref,...>::setAABB (compressed_node.h:669-685): the child boxes as they are
+        float* rec = (float*)(blob + CBVH_HEADER_BYTES) + (size_t)curr * (CBVH_FULL_NODE_BYTES / 4);
+        for (int m = 0; m < 4; m++) {
+          const Box3f& cbx = hier[l + 1][4 * k + m];
+          rec[0 + m] = cbx.lo[0]; rec[4 + m] = cbx.hi[0];
+          rec[8 + m] = cbx.lo[1]; rec[12 + m] = cbx.hi[1];
+          rec[16 + m] = cbx.lo[2]; rec[20 + m] = cbx.hi[2];
+        }
+      } else
+        cbvh_encode_node(hier[l][k], &hier[l + 1][4 * k], nodes[curr]);
       for (int m = 0; m < 4; m++) {
-        const Box3f cb = cbvh_decode_child(nodes[curr], hier[l][k], m);
+        const Box3f cb = mode == CBVH_FULL ? hier[l + 1][4 * k + m] : cbvh_decode_child(nodes[curr], hier[l][k], m); // getAABB: identity / decode
         hier[l + 1][4 * k + m] = cb;
         if (l == C - 1) {
           Box3f tb;

@@ -14,7 +14,7 @@
 
 namespace rtamd {
 
-enum CbvhMode { CBVH_BOX = 0, CBVH_LEAF = 1, CBVH_GRID = 2 };
+enum CbvhMode { CBVH_BOX = 0, CBVH_LEAF = 1, CBVH_GRID = 2, CBVH_FULL = 3 /* box semantics, float child boxes instead of 4-byte codes */ };
 
 struct Box3f
 {

@@ -87,7 +87,7 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
   // (The grid-cell kernel, whose leaves are always tested 8 lanes per ray, needs 118 VGPRs: four waves per SIMD fit, and a batch
   // alone on the chip is 10 % faster with four workgroups per CU; 0.169 -> 0.151 ms.)
-  const bool octOnly = A.kind == ACCEL_GRIDSOA || ((A.kind == ACCEL_CBVH_BOX || A.kind == ACCEL_CBVH_LEAF) && !p.cbvhLaneForm); // four waves per SIMD
+  const bool octOnly = A.kind == ACCEL_GRIDSOA || ((A.kind == ACCEL_CBVH_BOX || A.kind == ACCEL_CBVH_LEAF || A.kind == ACCEL_CBVH_FULL) && !p.cbvhLaneForm); // four waves per SIMD
   const uint32_t aloneBlocks = octOnly ? dev->tuneAloneBlocksOct : 2u;
   // with that fourth wave slot two workgroups per CU per batch are also the better grid in flight (eager, 40 steps: random rays
   // 13.3 -> 13.8 Grays/s, shadow rays 9.3 -> 9.8, camera rays 7.1 -> 7.7)

@@ -110,7 +110,7 @@ void build_cbvh(Scene* s, const std::vector<PatchGrid>& grids, Accel& A, CbvhMod
 {
   const unsigned C = s->compressionLevel;
   if (C < 1 || C > 5) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "compression level must be in 1..5 (local stack of compressed.h:510-512)");
-  A.kind = mode == CBVH_BOX ? ACCEL_CBVH_BOX : (mode == CBVH_LEAF ? ACCEL_CBVH_LEAF : ACCEL_CBVH_GRID);
+  A.kind = mode == CBVH_BOX ? ACCEL_CBVH_BOX : (mode == CBVH_LEAF ? ACCEL_CBVH_LEAF : (mode == CBVH_GRID ? ACCEL_CBVH_GRID : ACCEL_CBVH_FULL));
   const unsigned sub = 1u << C;
   const size_t stride = cbvh_blob_bytes(C, mode);
   A.blobStride = (uint32_t)stride;
@@ -172,7 +172,7 @@ void build_subdiv_accel(Scene* s)
   else if (name == "bvh4.compressed.box") mode = CBVH_BOX;
   else if (name == "bvh4.compressed.leaf") mode = CBVH_LEAF;
   else if (name == "bvh4.compressed.grid") mode = CBVH_GRID;
-  else if (name == "bvh4.compressed.full") RT_THROW(RTC_ERROR_INVALID_OPERATION, "bvh4.compressed.full (float nodes) is not provided by the device path");
+  else if (name == "bvh4.compressed.full") mode = CBVH_FULL; // scene.cpp:510
   else RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown subdiv accel " + name);
 
   std::vector<PatchGrid> grids;

@@ -80,6 +80,7 @@ inline hipError_t launch_trace(const LaunchParams& p, hipStream_t stream)
   case ACCEL_CBVH_BOX:
   case ACCEL_CBVH_LEAF:
   case ACCEL_CBVH_GRID:
+  case ACCEL_CBVH_FULL:
   case ACCEL_GRIDSOA: return launch_trace_subdiv(p, stream);
   default: return hipSuccess;
   }

@@ -201,7 +201,10 @@ struct GridCellLeaf
 // ---------------------------------------------------------------------------------------------------
 // fork: cBVH blob
 // ---------------------------------------------------------------------------------------------------
-enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2 };
+// MODE_FULL (subdiv_accel=bvh4.compressed.full, compressed.h:40,774): the box mode's cells and hits over quadtree nodes that hold
+// their four child boxes as floats (96 B, plane-major: lx[4] ux[4] ly[4] uy[4] lz[4] uz[4]) instead of a 4-byte code of planes
+// relative to the parent box - nothing to decode and nothing inherited from the parent, so a descent carries only the node index.
+enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2, MODE_FULL = 3 };
 
 // Node decode tables (compressed_node.h:488-510): border planes, mid planes, and their complements 1-x (the same
 // fp32 subtraction the reference performs per decode, done once).  They live in LDS: a lookup is one ds_read (~100
@@ -263,7 +266,9 @@ template <int LEVELS> struct CbvhGeom
   static __device__ __forceinline__ const uint32_t* nodes(const CbvhHeader* H) { return (const uint32_t*)((const uint8_t*)H + CBVH_HEADER_BYTES); }
   static __device__ __forceinline__ const uint8_t* leaves(const CbvhHeader* H) { return (const uint8_t*)H + CBVH_HEADER_BYTES + 4u * ELEMS; }
   static __device__ __forceinline__ const float* grid(const CbvhHeader* H) { return (const float*)((const uint8_t*)H + CBVH_HEADER_BYTES + 4u * ELEMS); }
+  static __device__ __forceinline__ const float* fullNode(const CbvhHeader* H, uint32_t curr) { return (const float*)((const uint8_t*)H + CBVH_HEADER_BYTES) + 24u * curr; }
 };
+typedef float f32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
 __device__ __forceinline__ void project3(const float* m, float x, float y, float z, float& ox, float& oy, float& oz)
 {
@@ -455,47 +460,68 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
                                           float bhz, WorkCounters& wc)
 {
   uint32_t cw[4] = {0u, 0u, 0u, 0u};
-  if constexpr (REM > 1) {
-    const u32x4_a4 q = *(const u32x4_a4*)(CbvhGeom<LEVELS>::nodes(c.H) + (4u * curr + 1u));
-    cw[0] = q.x; cw[1] = q.y; cw[2] = q.z; cw[3] = q.w;
-  } else if constexpr (MODE == MODE_LEAF) {
-    const u32x2_a4 q = *(const u32x2_a4*)(CbvhGeom<LEVELS>::leaves(c.H) + 2u * (4u * curr + 1u - CbvhGeom<LEVELS>::ELEMS)); // 4 cells x 2 bytes
-    cw[0] = q.x; cw[1] = q.y;
-  }
-  if (COUNT) wc.inner++;
-  // getNode, compressed_node.h:488-510
-  const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
-  const float* T = cbvh_tables();
-  const float lx0 = T[TBL_BORDER + ((w >> 5) & 7)] * dimX + blx;            // X1: children 0,2 lower
-  const float lx1 = T[TBL_MID + ((w >> 2) & 7)] * dimX + blx;               // X2: children 1,3 lower
-  const float ux0 = T[TBL_ONE_MINUS_MID + ((w >> 13) & 7)] * dimX + blx;    // X3: children 0,2 upper
-  const float ux1 = T[TBL_ONE_MINUS_BORDER + ((w >> 10) & 7)] * dimX + blx; // X4: children 1,3 upper
-  const float ly0 = T[TBL_BORDER + ((w >> 21) & 7)] * dimY + bly;           // Y1: children 0,1 lower
-  const float ly1 = T[TBL_MID + ((w >> 18) & 7)] * dimY + bly;              // Y2: children 2,3 lower
-  const float uy0 = T[TBL_ONE_MINUS_MID + ((w >> 29) & 7)] * dimY + bly;    // Y3: children 0,1 upper
-  const float uy1 = T[TBL_ONE_MINUS_BORDER + ((w >> 26) & 7)] * dimY + bly; // Y4: children 2,3 upper
-  const float lz = (float)(w & 3) * 0.25f * dimZ + blz;              // table3 = k/4
-  const float uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
-
-  // intersectNodeRobust (node_intersector1.h:351-368) on the two x columns, two y rows, one z slab
-  const bool negx = !(c.rnx >= 0.f), negy = !(c.rny >= 0.f), negz = !(c.rnz >= 0.f);
-  const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
-  const float rfx = c.rnx * ulp3, rfy = c.rny * ulp3, rfz = c.rnz * ulp3; // rdir_far (node_intersector1.h:116-118)
-  const float nX0 = ((negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((negx ? lx0 : ux0) - c.ox) * rfx;
-  const float nX1 = ((negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((negx ? lx1 : ux1) - c.ox) * rfx;
-  const float nY0 = ((negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((negy ? ly0 : uy0) - c.oy) * rfy;
-  const float nY1 = ((negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((negy ? ly1 : uy1) - c.oy) * rfy;
-  const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * rfz;
   float tN[4], tF[4];
   uint32_t d[4];
   uint32_t mask = 0;
+  float lx0, lx1, ux0, ux1, ly0, ly1, uy0, uy1, lz, uz; // coded modes: two x columns, two y rows, one z slab
+  f32x4_a16 FX0, FX1, FY0, FY1;                         // full mode: the four children's own x / y planes (cells need them for u, v)
+  if (COUNT) wc.inner++;
+  const bool negx = !(c.rnx >= 0.f), negy = !(c.rny >= 0.f), negz = !(c.rnz >= 0.f);
+  const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
+  const float rfx = c.rnx * ulp3, rfy = c.rny * ulp3, rfz = c.rnz * ulp3; // rdir_far (node_intersector1.h:116-118)
+  if constexpr (MODE == MODE_FULL) {
+    // Node<flavor::ref>::getNode (compressed_node.h:700-714): the stored boxes; intersectNodeRobust (node_intersector1.h:351-368) per child
+    const f32x4_a16* N = (const f32x4_a16*)CbvhGeom<LEVELS>::fullNode(c.H, curr);
+    FX0 = N[0]; FX1 = N[1]; FY0 = N[2]; FY1 = N[3];
+    const f32x4_a16 FZ0 = N[4], FZ1 = N[5];
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    tN[k] = fmaxf(fmaxf((k & 1) ? nX1 : nX0, (k & 2) ? nY1 : nY0), fmaxf(nZ, 0.f));
-    tF[k] = fminf(fminf((k & 1) ? fX1 : fX0, (k & 2) ? fY1 : fY0), fminf(fZ, c.travFar));
-    const bool h = tN[k] <= tF[k];
-    d[k] = h ? __float_as_uint(tN[k]) : 0xFFFFFFFFu;
-    mask |= h ? (1u << k) : 0u;
+    for (int k = 0; k < 4; k++) {
+      const float nX = ((negx ? FX1[k] : FX0[k]) - c.ox) * c.rnx, fX = ((negx ? FX0[k] : FX1[k]) - c.ox) * rfx;
+      const float nY = ((negy ? FY1[k] : FY0[k]) - c.oy) * c.rny, fY = ((negy ? FY0[k] : FY1[k]) - c.oy) * rfy;
+      const float nZ = ((negz ? FZ1[k] : FZ0[k]) - c.oz) * c.rnz, fZ = ((negz ? FZ0[k] : FZ1[k]) - c.oz) * rfz;
+      tN[k] = fmaxf(fmaxf(nX, nY), fmaxf(nZ, 0.f));
+      tF[k] = fminf(fminf(fX, fY), fminf(fZ, c.travFar));
+      const bool h = tN[k] <= tF[k];
+      d[k] = h ? __float_as_uint(tN[k]) : 0xFFFFFFFFu;
+      mask |= h ? (1u << k) : 0u;
+    }
+    lx0 = lx1 = ux0 = ux1 = ly0 = ly1 = uy0 = uy1 = lz = uz = 0.f;
+  } else {
+    if constexpr (REM > 1) {
+      const u32x4_a4 q = *(const u32x4_a4*)(CbvhGeom<LEVELS>::nodes(c.H) + (4u * curr + 1u));
+      cw[0] = q.x; cw[1] = q.y; cw[2] = q.z; cw[3] = q.w;
+    } else if constexpr (MODE == MODE_LEAF) {
+      const u32x2_a4 q = *(const u32x2_a4*)(CbvhGeom<LEVELS>::leaves(c.H) + 2u * (4u * curr + 1u - CbvhGeom<LEVELS>::ELEMS)); // 4 cells x 2 bytes
+      cw[0] = q.x; cw[1] = q.y;
+    }
+    // getNode, compressed_node.h:488-510
+    const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
+    const float* T = cbvh_tables();
+    lx0 = T[TBL_BORDER + ((w >> 5) & 7)] * dimX + blx;            // X1: children 0,2 lower
+    lx1 = T[TBL_MID + ((w >> 2) & 7)] * dimX + blx;               // X2: children 1,3 lower
+    ux0 = T[TBL_ONE_MINUS_MID + ((w >> 13) & 7)] * dimX + blx;    // X3: children 0,2 upper
+    ux1 = T[TBL_ONE_MINUS_BORDER + ((w >> 10) & 7)] * dimX + blx; // X4: children 1,3 upper
+    ly0 = T[TBL_BORDER + ((w >> 21) & 7)] * dimY + bly;           // Y1: children 0,1 lower
+    ly1 = T[TBL_MID + ((w >> 18) & 7)] * dimY + bly;              // Y2: children 2,3 lower
+    uy0 = T[TBL_ONE_MINUS_MID + ((w >> 29) & 7)] * dimY + bly;    // Y3: children 0,1 upper
+    uy1 = T[TBL_ONE_MINUS_BORDER + ((w >> 26) & 7)] * dimY + bly; // Y4: children 2,3 upper
+    lz = (float)(w & 3) * 0.25f * dimZ + blz;              // table3 = k/4
+    uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
+
+    // intersectNodeRobust (node_intersector1.h:351-368) on the two x columns, two y rows, one z slab
+    const float nX0 = ((negx ? ux0 : lx0) - c.ox) * c.rnx, fX0 = ((negx ? lx0 : ux0) - c.ox) * rfx;
+    const float nX1 = ((negx ? ux1 : lx1) - c.ox) * c.rnx, fX1 = ((negx ? lx1 : ux1) - c.ox) * rfx;
+    const float nY0 = ((negy ? uy0 : ly0) - c.oy) * c.rny, fY0 = ((negy ? ly0 : uy0) - c.oy) * rfy;
+    const float nY1 = ((negy ? uy1 : ly1) - c.oy) * c.rny, fY1 = ((negy ? ly1 : uy1) - c.oy) * rfy;
+    const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * rfz;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      tN[k] = fmaxf(fmaxf((k & 1) ? nX1 : nX0, (k & 2) ? nY1 : nY0), fmaxf(nZ, 0.f));
+      tF[k] = fminf(fminf((k & 1) ? fX1 : fX0, (k & 2) ? fY1 : fY0), fminf(fZ, c.travFar));
+      const bool h = tN[k] <= tF[k];
+      d[k] = h ? __float_as_uint(tN[k]) : 0xFFFFFFFFu;
+      mask |= h ? (1u << k) : 0u;
+    }
   }
   if (mask == 0) return;
   // nearest first, equal distances -> lower index first (compressed.h:690-749)
@@ -514,8 +540,13 @@ __device__ __forceinline__ void cbvh_node(CbvhCtx& c, uint32_t curr, uint32_t w,
 #pragma unroll
     for (int q = 1; q < 4; q++) rr = ((mask >> q) & 1u) && rank[q] == (uint32_t)k ? q : rr;
     if (!(((mask >> rr) & 1u) && rank[rr] == (uint32_t)k)) rr = 0;
-    const float cbx0 = (rr & 1) ? lx1 : lx0, cbx1 = (rr & 1) ? ux1 : ux0;
-    const float cby0 = (rr & 2) ? ly1 : ly0, cby1 = (rr & 2) ? uy1 : uy0;
+    float cbx0 = (rr & 1) ? lx1 : lx0, cbx1 = (rr & 1) ? ux1 : ux0;
+    float cby0 = (rr & 2) ? ly1 : ly0, cby1 = (rr & 2) ? uy1 : uy0;
+    if constexpr (MODE == MODE_FULL && REM == 1) {
+      cbx0 = FX0[0]; cbx1 = FX1[0]; cby0 = FY0[0]; cby1 = FY1[0];
+#pragma unroll
+      for (int q = 1; q < 4; q++) { cbx0 = rr == q ? FX0[q] : cbx0; cbx1 = rr == q ? FX1[q] : cbx1; cby0 = rr == q ? FY0[q] : cby0; cby1 = rr == q ? FY1[q] : cby1; }
+    }
     const uint32_t child = 4u * curr + 1u + (uint32_t)rr;
     uint32_t cword;
     if constexpr (REM == 1) cword = ((rr & 2) ? cw[1] : cw[0]) >> ((rr & 1) * 16);
@@ -587,20 +618,27 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
   const uint32_t q = lid & 3u;
   // this lane's child: its node word / its cell's two height bytes, requested before anything else (one 16-byte / 8-byte access per quad)
   uint32_t cw = 0u;
-  if constexpr (REM > 1) cw = CbvhGeom<LEVELS>::nodes(c.H)[4u * curr + 1u + q];
-  else if constexpr (MODE == MODE_LEAF) cw = ((const uint16_t*)CbvhGeom<LEVELS>::leaves(c.H))[4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS];
+  float lx, ux, ly, uy, lz, uz;
   if (COUNT && q == 0u) wc.inner++;
-  // getNode, compressed_node.h:488-510, the planes of child q only (x column = q & 1, y row = q >> 1)
-  const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
-  const float* T = cbvh_tables();
-  const uint32_t xl = (q & 1u) ? TBL_MID + ((w >> 2) & 7u) : TBL_BORDER + ((w >> 5) & 7u);
-  const uint32_t xu = (q & 1u) ? TBL_ONE_MINUS_BORDER + ((w >> 10) & 7u) : TBL_ONE_MINUS_MID + ((w >> 13) & 7u);
-  const uint32_t yl = (q & 2u) ? TBL_MID + ((w >> 18) & 7u) : TBL_BORDER + ((w >> 21) & 7u);
-  const uint32_t yu = (q & 2u) ? TBL_ONE_MINUS_BORDER + ((w >> 26) & 7u) : TBL_ONE_MINUS_MID + ((w >> 29) & 7u);
-  const float lx = T[xl] * dimX + blx, ux = T[xu] * dimX + blx;
-  const float ly = T[yl] * dimY + bly, uy = T[yu] * dimY + bly;
-  const float lz = (float)(w & 3) * 0.25f * dimZ + blz;
-  const float uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
+  if constexpr (MODE == MODE_FULL) {
+    // Node<flavor::ref>::getNode (compressed_node.h:700-714): child q's stored box, six 16-byte accesses per quad
+    const float* N = CbvhGeom<LEVELS>::fullNode(c.H, curr) + q;
+    lx = N[0]; ux = N[4]; ly = N[8]; uy = N[12]; lz = N[16]; uz = N[20];
+  } else {
+    if constexpr (REM > 1) cw = CbvhGeom<LEVELS>::nodes(c.H)[4u * curr + 1u + q];
+    else if constexpr (MODE == MODE_LEAF) cw = ((const uint16_t*)CbvhGeom<LEVELS>::leaves(c.H))[4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS];
+    // getNode, compressed_node.h:488-510, the planes of child q only (x column = q & 1, y row = q >> 1)
+    const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
+    const float* T = cbvh_tables();
+    const uint32_t xl = (q & 1u) ? TBL_MID + ((w >> 2) & 7u) : TBL_BORDER + ((w >> 5) & 7u);
+    const uint32_t xu = (q & 1u) ? TBL_ONE_MINUS_BORDER + ((w >> 10) & 7u) : TBL_ONE_MINUS_MID + ((w >> 13) & 7u);
+    const uint32_t yl = (q & 2u) ? TBL_MID + ((w >> 18) & 7u) : TBL_BORDER + ((w >> 21) & 7u);
+    const uint32_t yu = (q & 2u) ? TBL_ONE_MINUS_BORDER + ((w >> 26) & 7u) : TBL_ONE_MINUS_MID + ((w >> 29) & 7u);
+    lx = T[xl] * dimX + blx; ux = T[xu] * dimX + blx;
+    ly = T[yl] * dimY + bly; uy = T[yu] * dimY + bly;
+    lz = (float)(w & 3) * 0.25f * dimZ + blz;
+    uz = (1.f - (float)((w >> 16) & 3) * 0.25f) * dimZ + blz;
+  }
   // intersectNodeRobust (node_intersector1.h:351-368) for this child
   const bool negx = !(c.rnx >= 0.f), negy = !(c.rny >= 0.f), negz = !(c.rnz >= 0.f);
   const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
@@ -626,6 +664,10 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
   if constexpr (REM > 1) {
     for (uint32_t k = 0; k < nhit; k++) {
       const uint32_t src = (uint32_t)__ffs(quad_ballot(pos == k, lid)) - 1u; // the child visited k-th
+      if constexpr (MODE == MODE_FULL) { // the child node holds its own children's boxes: only its index goes down
+        quad_node<MODE, LEVELS, REM - 1, COUNT>(c, lid, 4u * curr + 1u + src, 0u, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, wc);
+        continue;
+      }
       const float cbx0 = quad_getf(lx, src, lid), cbx1 = quad_getf(ux, src, lid);
       const float cby0 = quad_getf(ly, src, lid), cby1 = quad_getf(uy, src, lid);
       const uint32_t cword = quad_get(cw, src, lid);
@@ -656,7 +698,7 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
         quad_commit(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(ct, src, lid));
       }
     }
-  } else if constexpr (MODE == MODE_BOX) { // voxel, compressed.h:614-654: the box entry point is the hit
+  } else if constexpr (MODE == MODE_BOX || MODE == MODE_FULL) { // voxel, compressed.h:614-654: the box entry point is the hit
     float cu = 0.f, cv = 0.f;
     if (pos != 4u) {
       const uint32_t idx = 4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS;
@@ -821,7 +863,8 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
 #endif
   // (grid mode walks with the world ray and its hit in registers - its triangle tests feed each other through ray.tfar - and stays at three;
   // the lane-per-ray form keeps every level's parent box in registers: three waves up to C = 3, two beyond)
-  static constexpr int MIN_WAVES = !QUAD ? (LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD) : (MODE == MODE_GRID ? (LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD) : TRACE_CBVH_MIN_WAVES(LEVELS));
+  // (full mode, quad form: a descent carries only the node index - 113..117 VGPRs at every level: four waves throughout)
+  static constexpr int MIN_WAVES = !QUAD ? (LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD) : (MODE == MODE_GRID ? (LEVELS >= 4 ? 2 : TRACE_MIN_WAVES_PER_SIMD) : (MODE == MODE_FULL ? 4 : TRACE_CBVH_MIN_WAVES(LEVELS)));
   static __device__ __forceinline__ void prepare() { cbvh_tables_init(); }
 
   template <bool OCCLUDED, bool COUNT>
@@ -960,6 +1003,7 @@ hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream)
   case ACCEL_CBVH_BOX: return dev::launch_cbvh<dev::MODE_BOX>(p, stream, p.cbvhLevels);
   case ACCEL_CBVH_LEAF: return dev::launch_cbvh<dev::MODE_LEAF>(p, stream, p.cbvhLevels);
   case ACCEL_CBVH_GRID: return dev::launch_cbvh<dev::MODE_GRID>(p, stream, p.cbvhLevels);
+  case ACCEL_CBVH_FULL: return dev::launch_cbvh<dev::MODE_FULL>(p, stream, p.cbvhLevels);
   default: return hipErrorInvalidValue;
   }
 }

@@ -32,8 +32,8 @@ orc_scene* orc_scene_new_triangles(const float* verts, size_t nverts, const uint
 void orc_scene_free(orc_scene* s);
 
 /* Subdivision scenes over leaf records exported by the product (rtcamdGetAccelData kind 2; formats in
- * embree-compressed_amd/csrc/accel.h).  mode 2: eager grid cells (GridCell, stride 160); mode 3/4/5: fork cBVH blobs
- * (box / leaf / grid) of `stride` bytes with `levels` = compression level C.  The oracle builds its own BVH over them. */
+ * embree-compressed_amd/csrc/accel.h).  mode 2: eager grid cells (GridCell, stride 160); mode 3/4/5/6: fork cBVH blobs
+ * (box / leaf / grid / full) of `stride` bytes with `levels` = compression level C.  The oracle builds its own BVH over them. */
 orc_scene* orc_scene_new_subdiv(const void* blobs, size_t stride, size_t count, int mode, unsigned levels);
 /* Same, but traversing the product's own outer BVH8 (rtcamdGetAccelData kind 0 + rtcamdGetAccelRoot): required for the
  * order-dependent fork modes box / leaf, see subdiv_oracle.inc. */

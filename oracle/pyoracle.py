@@ -131,7 +131,7 @@ class TriangleScene:
 
 class SubdivScene(TriangleScene):
     """Scene over leaf records exported by the product (rtcamdGetAccelData kind 2).
-    mode 2: eager grid cells (stride 160); 3/4/5: fork cBVH blobs box/leaf/grid."""
+    mode 2: eager grid cells (stride 160); 3/4/5/6: fork cBVH blobs box/leaf/grid/full."""
 
     def __init__(self, blobs, stride, mode, levels=3, qnodes=None, root=None):
         """qnodes/root given: traverse the product's outer BVH8 (same visiting order as the device kernels)."""

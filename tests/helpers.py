@@ -83,7 +83,10 @@ def random_rays_np(m, lo, hi, seed):
     return p1, d
 
 
-FORK_MODES = ("bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.grid")
+FORK_MODES = ("bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.grid", "bvh4.compressed.full")
+# oracle mode numbers (oracle/embree_oracle.h) and the modes whose result depends on the order blobs are reached in (same-tree oracle)
+FORK_ORACLE_MODE = {"default": 2, "bvh4.compressed.box": 3, "bvh4.compressed.leaf": 4, "bvh4.compressed.grid": 5, "bvh4.compressed.full": 6}
+ORDERED_FORK = ("bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.full")
 
 
 def fork_parity_stats(got, want, rtol=1e-4):

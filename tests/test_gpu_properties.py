@@ -87,7 +87,7 @@ def test_full_size_properties(rtc, bomberman, kind):
     dev.release()
 
 
-@pytest.mark.parametrize("kind", ["tri", "tri.moeller", "bvh4.compressed.leaf", "default"])
+@pytest.mark.parametrize("kind", ["tri", "tri.moeller", "bvh4.compressed.leaf", "bvh4.compressed.full", "default"])
 def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     """The child-parallel (octet) node and leaf steps (trace_loop.hip.h: 8 lanes per ray, taken when few lanes of a wave
     have node work / from a few rays waiting at a triangle or grid-cell leaf on) against the lane-per-ray steps, and the
@@ -115,7 +115,7 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     # reference = lane-per-ray steps only.  Triangle leaves and grid cells have no lane-per-ray leaf code in the lane kernel
     # any more (they are always tested 8 lanes per ray): their reference comes from the ray-pool kernel, which runs
     # TriLeaf::intersect / GridCellLeaf::intersect, one lane per ray
-    monkeypatch.setenv("RTAMD_KERNEL", "lane" if kind == "bvh4.compressed.leaf" else "pool")
+    monkeypatch.setenv("RTAMD_KERNEL", "lane" if kind.startswith("bvh4.compressed") else "pool")
     monkeypatch.setenv("RTAMD_OCT_MAX", "0")  # knobs are read when the device is created
     monkeypatch.setenv("RTAMD_OCT_LEAF", "0")
     monkeypatch.setenv("RTAMD_CULL", "0")  # no root cull pre-pass: every ray is fetched by the traversal kernel itself

@@ -1,7 +1,7 @@
 """BASELINE config 5 (pathtracer): incoherent secondary rays and shadow rays that START ON the geometry, recorded
 wavefront-style from a primary pass (SURVEY.md section 8d "Config 5").  Origins on the surface are the hard case for
 parity: self-hits are avoided only by tnear (pathtracer_device.cpp uses tnear = 0.001), so GPU and oracle must agree
-on grazing and coplanar configurations.  Triangles (robust and fast path), the eager subdivision path and the fork's three
+on grazing and coplanar configurations.  Triangles (robust and fast path), the eager subdivision path and the fork's four
 compressed modes (same-tree oracle for the order-dependent box / leaf modes, both arithmetic modes: helpers.check_fork_parity)."""
 import importlib
 
@@ -77,7 +77,7 @@ def test_secondary_and_shadow_rays_from_surface_points(rtc, po, bomberman, kind)
     dev.release()
 
 
-@pytest.mark.parametrize("accel,mode", [("bvh4.compressed.leaf", 4), ("bvh4.compressed.box", 3), ("bvh4.compressed.grid", 5)])
+@pytest.mark.parametrize("accel,mode", [("bvh4.compressed.leaf", 4), ("bvh4.compressed.box", 3), ("bvh4.compressed.grid", 5), ("bvh4.compressed.full", 6)])
 def test_secondary_and_shadow_rays_on_the_compressed_accels(rtc, po, bomberman, accel, mode):
     """Config 5 on the metric's accel family: bounce rays recorded from a 640x360 camera frame of the SAME accel, traced with
     rtcIntersect1M; shadow rays with rtcOccluded1M, whose fork semantics are "occluded iff the outer traversal reaches a leaf"
@@ -90,7 +90,7 @@ def test_secondary_and_shadow_rays_on_the_compressed_accels(rtc, po, bomberman, 
     sc.set_levels(6, 3)
     sc.commit()
     st = sc.stats()
-    same_tree = mode in (3, 4)
+    same_tree = mode in (3, 4, 6)
     orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], mode, 3, qnodes=sc.accel_data(0) if same_tree else None, root=sc.accel_root() if same_tree else None)
     raw = rg.make_primary_rays(640, 360)
     prim = rtc.aligned_rayhits(raw.shape[0])

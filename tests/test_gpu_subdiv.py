@@ -19,7 +19,8 @@ from helpers import INVALID, check_fork_parity, compare_hits, fill_rays, random_
 
 pytestmark = pytest.mark.gpu
 
-ACCELS = {"default": 2, "bvh4.compressed.box": 3, "bvh4.compressed.leaf": 4, "bvh4.compressed.grid": 5}
+ACCELS = {"default": 2, "bvh4.compressed.box": 3, "bvh4.compressed.leaf": 4, "bvh4.compressed.grid": 5, "bvh4.compressed.full": 6}
+ORDERED = ("bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.full")  # box-type hits: order dependent
 
 
 def _build(rtc, accel, verts, fs, fi, L, Cl, extra=None, displacement=None):
@@ -39,7 +40,7 @@ def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
     verts, fs, fi = bomberman
     dev, sc = _build(rtc, accel, verts, fs, fi, L, Cl)
     st = sc.stats()
-    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+    if accel in ORDERED:
         # order-dependent modes: the oracle must reach the blobs in the same order -> it walks the product's outer BVH8
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
     else:
@@ -69,7 +70,7 @@ def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
         occ[f] = src[f]
     wocc = occ.copy()
     sc.occluded1M(occ)
-    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+    if accel in ORDERED:
         # the any-hit stub does not depend on visiting order: check it against the oracle's own full-precision tree
         # (the product tests the blob's exact bounds, like the reference's BVH4 leaf boxes; its quantized BVH8 boxes
         # are only a conservative pre-filter)
@@ -165,7 +166,7 @@ def test_displaced_cube_with_ground_plane(rtc, po, accel):
     dev.release()
 
 
-@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf"])
+@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf", "bvh4.compressed.full"])
 def test_primary_rays_config4(rtc, po, bomberman, accel):
     """BASELINE config 4: coherent camera rays of build/bomberman.ecs (here 480x270, tile order), almost all of which
     hit the scene, so leaves dominate the work; same-tree oracle (the fork's leaf mode is order dependent)."""
@@ -236,7 +237,7 @@ def test_primary_rays_config4_full_size(rtc, po, bomberman, accel):
     dev.release()
 
 
-@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf", "bvh4.compressed.box", "bvh4.compressed.grid"])
+@pytest.mark.parametrize("accel", ["default", "bvh4.compressed.leaf", "bvh4.compressed.box", "bvh4.compressed.grid", "bvh4.compressed.full"])
 def test_config3_displacement_geometry_scene(rtc, po, accel):
     """BASELINE config 3 as the tutorial defines it (tutorials/displacement_geometry/displacement_geometry_device.cpp): the
     6-quad subdivision cube at rtcSetSceneLevels(6, 4) with the Perlin-noise displacement shader (the reference's noise.cpp
@@ -264,7 +265,7 @@ def test_config3_displacement_geometry_scene(rtc, po, accel):
     sc.set_levels(L, Cl)
     sc.commit()
     st = sc.stats()
-    same_tree = accel in ("bvh4.compressed.box", "bvh4.compressed.leaf")
+    same_tree = accel in ORDERED
     orc_s = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0) if same_tree else None,
                            root=sc.accel_root() if same_tree else None)
     orc_t = po.TriangleScene(gv, gt, 0, np.full(2, g_tri, np.uint32), np.arange(2, dtype=np.uint32))
@@ -325,7 +326,7 @@ def test_non_quad_faces_parity(rtc, po, accel):
     fi = np.concatenate([np.array(f, np.uint32) for f in F])
     dev, sc = _build(rtc, accel, V, fs, fi, 4, 2)
     st = sc.stats()
-    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+    if accel in ORDERED:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 2, qnodes=sc.accel_data(0), root=sc.accel_root())
     else:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], 2)
@@ -382,15 +383,15 @@ def test_gpu_reproduces_the_subdiv_golden_fixture(rtc, po, bomberman, accel):
     dev.release()
 
 
-@pytest.mark.parametrize("accel", ["bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.grid"])
+@pytest.mark.parametrize("accel", ["bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.grid", "bvh4.compressed.full"])
 @pytest.mark.parametrize("L,Cl", [(4, 1), (5, 4), (6, 5)])
 def test_compression_levels_parity(rtc, po, bomberman, accel, L, Cl):
     """The cBVH kernels are instantiated per compression level C (node / cell / grid addresses are compile-time offsets from
-    the blob header): the shallowest and the two deepest levels, all three modes, against the oracle's stack-based walk."""
+    the blob header): the shallowest and the two deepest levels, all four modes, against the oracle's stack-based walk."""
     verts, fs, fi = bomberman
     dev, sc = _build(rtc, accel, verts, fs, fi, L, Cl)
     st = sc.stats()
-    if accel in ("bvh4.compressed.box", "bvh4.compressed.leaf"):
+    if accel in ORDERED:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl, qnodes=sc.accel_data(0), root=sc.accel_root())
     else:
         orc = po.SubdivScene(sc.accel_data(2), st["primBytes"], ACCELS[accel], Cl)

@@ -136,6 +136,77 @@ def _morton(i):
     return x, y
 
 
+def test_full_precision_nodes_hold_the_merged_cell_boxes(rtc, bomberman):
+    """subdiv_accel=bvh4.compressed.full (compressed.h:40: Node<flavor::ref,...>, float boxes[4][6]; here plane-major, 96 B):
+    the header is the box mode's byte for byte except for `box` / world bounds (made from the stored instead of the re-decoded
+    cell boxes), a last-level child box is the bounding box of its cell's four projected vertices, an inner child box the union
+    of its four children (build_box_hierarchy, compressed.h:381-405), and every float box lies inside the box the 4-byte code
+    of the box mode decodes to for the same child (the quantizer only ever widens)."""
+    verts, fs, fi = bomberman
+    L, Cl = 4, 2
+    blobs = {}
+    for mode in ("bvh4.compressed.full", "bvh4.compressed.box"):
+        dev = rtc.Device(f"gpu=none,keep_grids=1,subdiv_accel={mode}")
+        sc = rtc.Scene(dev)
+        sc.add_subdiv(verts, fs, fi)
+        sc.set_levels(L, Cl)
+        sc.commit()
+        st = sc.stats()
+        blobs[mode] = sc.accel_data(2).reshape(-1, st["primBytes"]).copy()
+        if mode.endswith("full"):
+            g = _grids(sc, L)
+            assert st["accelKind"] == 7
+        sc.release()
+        dev.release()
+    elems = (4 ** Cl - 1) // 3
+    F, B = blobs["bvh4.compressed.full"], blobs["bvh4.compressed.box"]
+    assert F.shape[1] == (224 + 96 * elems + 15) // 16 * 16 and len(F) == len(B)
+    n, sub = 2 ** L, 2 ** Cl
+    rng = np.random.RandomState(1)
+    for k in rng.choice(len(F), 200, replace=False):
+        H, HB = F[k][:224].view(HDR_DT)[0], B[k][:224].view(HDR_DT)[0]
+        for f in ("geomID", "primID", "uv0", "uv1", "rcp_edges", "elems", "grid_width", "levels", "space", "proj", "iproj"):
+            assert np.array_equal(H[f], HB[f]), f
+        nodes = F[k][224:224 + 96 * elems].view(np.float32).reshape(elems, 6, 4)  # [node][lx ux ly uy lz uz][child]
+        words = B[k][224:224 + 4 * elems].view(np.uint32)
+        x0, y0 = int(round(H["uv0"][0] * n)), int(round(H["uv0"][1] * n))
+        G = g[int(H["primID"])]
+        P = np.stack([G[0][y0:y0 + sub + 1, x0:x0 + sub + 1], G[1][y0:y0 + sub + 1, x0:x0 + sub + 1], G[2][y0:y0 + sub + 1, x0:x0 + sub + 1]], -1).astype(np.float64)
+        loc = P @ H["space"].reshape(3, 3).astype(np.float64).T
+        hom = np.concatenate([loc[..., :2], np.ones(loc.shape[:2] + (1,))], -1) @ H["proj"].reshape(3, 3).astype(np.float64).T
+        pr = np.concatenate([hom[..., :2] / hom[..., 2:3], loc[..., 2:3]], -1)
+
+        def child_box(idx, r):
+            return nodes[idx, 0::2, r], nodes[idx, 1::2, r]
+
+        rootq = (np.array([-1, -1, HB["box"][0]], np.float32), np.array([1, 1, HB["box"][1]], np.float32))
+        stack = [(0, rootq)]
+        zlo, zhi = np.inf, -np.inf
+        while stack:
+            idx, qbox = stack.pop()
+            for r in range(4):
+                lo, hi = child_box(idx, r)
+                qlo, qhi = _decode_child(int(words[idx]), qbox, r)
+                # quantized box contains the float box - up to rounding of the decode, and up to the root's nominal [-1,1]^2
+                # (compressed.h:517-519), which the rescaled projection meets only to a few 1e-4
+                eps = 1e-3 * np.abs(qhi - qlo) + 1e-6 * np.maximum(np.maximum(np.abs(qlo), np.abs(qhi)), 1.0)
+                assert np.all(lo >= qlo - eps) and np.all(hi <= qhi + eps)
+                child = 4 * idx + 1 + r
+                if child < elems:
+                    clo = np.min(nodes[child, 0::2, :], axis=1)
+                    chi = np.max(nodes[child, 1::2, :], axis=1)
+                    assert np.array_equal(lo, clo) and np.array_equal(hi, chi)  # union of the four children, exactly
+                    stack.append((child, (qlo, qhi)))
+                else:
+                    cx, cy = _morton(child - elems)
+                    q = pr[cy:cy + 2, cx:cx + 2].reshape(4, 3)
+                    # (the encoder projects in fp32 from world coordinates of a few hundred: ~1e-4 of the [-1,1] window)
+                    tol = np.array([5e-4, 5e-4, 2e-5 * max(1.0, float(np.abs(q[:, 2]).max()))])
+                    assert np.all(np.abs(lo - q.min(0)) <= tol) and np.all(np.abs(hi - q.max(0)) <= tol)  # tight around the cell
+                    zlo, zhi = min(zlo, lo[2]), max(zhi, hi[2])
+        assert H["box"][0] == np.float32(zlo) and H["box"][1] == np.float32(zhi)  # frustum z range = the stored cells' (compressed.h:277-292)
+
+
 @pytest.mark.parametrize("mode,Cl", [("bvh4.compressed.leaf", 3), ("bvh4.compressed.box", 2), ("bvh4.compressed.grid", 3)])
 def test_cbvh_encoder_is_conservative(rtc, bomberman, mode, Cl):
     """Decode every blob with the tables of compressed_node.h: each cell's decoded box (in the blob's projected
@@ -274,7 +345,7 @@ def test_leaf_quantiser_matches_the_forks_header(rtc, po):
             assert np.array_equal(out, np.array(want, np.float32))
 
 
-@pytest.mark.parametrize("accel,mode", [("default", 2), ("bvh4.compressed.box", 3), ("bvh4.compressed.leaf", 4), ("bvh4.compressed.grid", 5)])
+@pytest.mark.parametrize("accel,mode", [("default", 2), ("bvh4.compressed.box", 3), ("bvh4.compressed.leaf", 4), ("bvh4.compressed.grid", 5), ("bvh4.compressed.full", 6)])
 def test_subdiv_golden_fixture_is_reproduced(rtc, po, bomberman, accel, mode):
     """tests/golden/bomberman_subdiv_hits.npz (tests/golden/make_golden_subdiv.py): host pipeline (tessellator, encoders,
     outer BVH) + oracle reproduce the committed hits; guards all of them against silent changes."""
@@ -286,7 +357,7 @@ def test_subdiv_golden_fixture_is_reproduced(rtc, po, bomberman, accel, mode):
     sc.add_subdiv(verts, fs, fi)
     sc.set_levels(int(g["level"]), int(g["compression"]))
     sc.commit()
-    ordered = mode in (3, 4)
+    ordered = mode in (3, 4, 6)
     orc = po.SubdivScene(sc.accel_data(2), sc.stats()["primBytes"], mode, int(g["compression"]),
                          qnodes=sc.accel_data(0) if ordered else None, root=sc.accel_root() if ordered else None)
     rays = po.make_random_rays(int(g["count"]), verts.min(0), verts.max(0), seed=int(g["seed"]))

@@ -11,6 +11,7 @@ run --workload eager
 run --workload tri
 run --workload cbvh.box
 run --workload cbvh.grid
+run --workload cbvh.full
 run --workload cbvh.leaf --rays-kind primary
 run --workload eager --rays-kind primary
 run --workload tri --rays-kind primary
