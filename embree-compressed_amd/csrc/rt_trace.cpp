@@ -32,7 +32,7 @@ static bool is_device_pointer(const void* p) { return pointer_device(p) >= 0; }
 // after the kernels (word 1 of a queue = rays that survived the root cull pre-pass, word 2 = valid rays the pre-pass tested)
 static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
                       WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr, uint32_t* cullCountsOut = nullptr,
-                      bool coherent = false)
+                      bool coherent = false, const uint32_t* exclT = nullptr)
 {
   Device* dev = s->device;
   Device::GpuShard& sh = *dev->shards[si];
@@ -74,6 +74,7 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : (A.kind == ACCEL_GRIDSOA ? 24u : 16u);
   p.exclOffsets = exclOffsets;
   p.exclPairs = exclPairs;
+  p.exclT = exclT;
   p.overflow = sh.overflowDev;
   // {context, queue heads, launch, event} as one unit: concurrent callers on device-resident batches must not pick the same
   // context (its event still reads "finished" until the new launch has recorded it).  The stream is read once.
@@ -123,23 +124,31 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
 // them.  Two-phase scheme: the kernel finds the closest candidate of every ray; the host runs the geometry's filter and
 // then the context filter on it with the reference's argument protocol (ray.tfar = candidate distance, N = 1); an
 // accepted candidate is the ray's result; a rejected one is put on the ray's exclusion list and the ray is traced again
-// (only those rays, compacted), the kernel skipping listed triangles, until every ray has an accepted hit or none.
+// (only those rays, compacted), the kernel skipping listed candidates, until every ray has an accepted hit or none.
 // For pure accept/reject filters this is the reference's result: rejected candidates never shorten the ray there either,
 // so the closest accepted candidate wins.  The callbacks see the candidates of a ray in order of distance instead of
 // traversal order, each at most once.  Occlusion filters run the same loop on closest candidates (any accepted candidate
-// = occluded).  Triangle geometry only: a subdivision patch's triangles share one primID, so they cannot be excluded one
-// by one.
+// = occluded).
+// Subdivision geometry (round 2):
+//  * eager grid cells (GridSOAIntersector1 -> Intersect1EpilogMU / Occluded1EpilogMU, grid_soa_intersector1.h:61,83,
+//    intersector_epilog.h:460-600: every triangle of a patch is offered to the filter on its own, with the PATCH's geomID / primID):
+//    a candidate is identified by (geomID, primID, bits of t) - kernels are deterministic, the same triangle gives the same t
+//    when the ray is traced again.  Two triangles of one patch hit at a bit-identical distance (a ray through their shared edge)
+//    are rejected together, where the reference would offer both.
+//  * the fork's compressed modes never call a filter: CompressedBVHIntersector1::intersect writes the hit itself and occluded()
+//    is a stub (compressed.h:454-756, no runIntersectionFilter1 anywhere in compressed*.h).  Hits on such an accel are accepted
+//    without a callback, geometry and context filter alike; for any-hit queries the stub pass runs first, unfiltered.
 static const unsigned FILTER_MAX_ROUNDS = 256;
 
 static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx)
 {
   Device* dev = s->device;
-  if (s->subdivFilter || ((ctx && ctx->filter) && s->subdivAccel.kind != ACCEL_NONE && s->subdivAccel.root != REF_EMPTY))
-    RT_THROW(RTC_ERROR_INVALID_OPERATION, "filter functions on subdivision geometry are not supported by the MI355X path");
   RTCIntersectContext localCtx;
   if (!ctx) { memset(&localCtx, 0, sizeof(localCtx)); localCtx.instID[0] = RTC_INVALID_GEOMETRY_ID; ctx = &localCtx; }
   const uint32_t instID = ctx->instID[0];
   const uint32_t recIn = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
+  const bool haveSubdiv = s->subdivAccel.kind != ACCEL_NONE && s->subdivAccel.root != REF_EMPTY;
+  const bool forkAccel = haveSubdiv && s->subdivAccel.kind != ACCEL_GRIDSOA; // no filter calls on these (see above)
   std::lock_guard<std::mutex> lock(dev->launchMutex);
   // the host filter loop runs on the first shard (its rounds are latency bound, not throughput bound)
   Device::GpuShard& sh = dev->primary();
@@ -168,44 +177,82 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
       memcpy(&W[i].hit, src + (size_t)i * byteStride + sizeof(RTCRay), sizeof(RTCHit));
     if (W[i].ray.tnear <= W[i].ray.tfar && !(occluded && W[i].ray.tfar < 0.0f)) act.push_back(i);
   }
-  std::vector<std::vector<uint2>> excl(M);
-  std::vector<uint32_t> offsets, next;
-  std::vector<uint2> pairs;
+  if (occluded && forkAccel && !act.empty()) {
+    // the stub any-hit pass of the fork's accel, unfiltered; the filter loop below then only sees the triangle accel
+    const uint32_t K = (uint32_t)act.size();
+    const size_t bytes = (size_t)K * sizeof(RTCRay);
+    sh.ensureStaging(bytes);
+    RTCRay* h = (RTCRay*)sh.stageHost;
+    for (uint32_t k = 0; k < K; k++) h[k] = W[act[k]].ray;
+    HIP_CHECK(hipMemcpyAsync(sh.stageDev, h, bytes, hipMemcpyHostToDevice, sh.stream));
+    launch_on(s, s->subdivAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRay), true, instID, nullptr);
+    HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
+    HIP_CHECK(hipStreamSynchronize(sh.stream));
+    std::vector<uint32_t> rest;
+    for (uint32_t k = 0; k < K; k++) {
+      if (h[k].tfar < 0.0f) W[act[k]].ray.tfar = -std::numeric_limits<float>::infinity();
+      else rest.push_back(act[k]);
+    }
+    act.swap(rest);
+  }
+  struct Rejected { uint32_t geomID, primID, tbits; };
+  std::vector<std::vector<Rejected>> exclTri(M), exclSub(M);
+  std::vector<uint32_t> offT, offS, tS, next;
+  std::vector<uint2> pairsT, pairsS;
   void* dExcl = nullptr;
   size_t dExclBytes = 0;
   auto freeExcl = [&]() { if (dExcl) hipFree(dExcl); dExcl = nullptr; };
+  auto a16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
   try {
     for (unsigned round = 0; !act.empty() && round < FILTER_MAX_ROUNDS; round++) {
       const uint32_t K = (uint32_t)act.size();
       const size_t bytes = (size_t)K * sizeof(RTCRayHit);
       sh.ensureStaging(bytes);
       RTCRayHit* h = (RTCRayHit*)sh.stageHost;
-      offsets.assign(K + 1, 0);
-      pairs.clear();
+      offT.assign(K + 1, 0);
+      offS.assign(K + 1, 0);
+      pairsT.clear(); pairsS.clear(); tS.clear();
       for (uint32_t k = 0; k < K; k++) {
         h[k] = W[act[k]];
-        offsets[k] = (uint32_t)pairs.size();
-        pairs.insert(pairs.end(), excl[act[k]].begin(), excl[act[k]].end());
+        offT[k] = (uint32_t)pairsT.size();
+        offS[k] = (uint32_t)pairsS.size();
+        for (const Rejected& e : exclTri[act[k]]) pairsT.push_back(make_uint2(e.geomID, e.primID));
+        for (const Rejected& e : exclSub[act[k]]) { pairsS.push_back(make_uint2(e.geomID, e.primID)); tS.push_back(e.tbits); }
       }
-      offsets[K] = (uint32_t)pairs.size();
-      const uint32_t* dOff = nullptr;
-      const uint2* dPairs = nullptr;
-      if (!pairs.empty()) {
-        const size_t offBytes = ((size_t)(K + 1) * 4 + 15) & ~(size_t)15, need = offBytes + pairs.size() * sizeof(uint2);
+      offT[K] = (uint32_t)pairsT.size();
+      offS[K] = (uint32_t)pairsS.size();
+      const uint32_t *dOffT = nullptr, *dOffS = nullptr, *dTS = nullptr;
+      const uint2 *dPairsT = nullptr, *dPairsS = nullptr;
+      if (!pairsT.empty() || !pairsS.empty()) {
+        const size_t offBytes = a16((size_t)(K + 1) * 4);
+        const size_t oPT = 2 * offBytes, oPS = oPT + a16(pairsT.size() * sizeof(uint2)), oTS = oPS + a16(pairsS.size() * sizeof(uint2));
+        const size_t need = oTS + a16(tS.size() * 4);
         if (need > dExclBytes) {
           HIP_CHECK(hipStreamSynchronize(sh.stream));
           freeExcl();
           dExclBytes = need * 2;
           HIP_CHECK(hipMalloc(&dExcl, dExclBytes));
         }
-        HIP_CHECK(hipMemcpyAsync(dExcl, offsets.data(), (size_t)(K + 1) * 4, hipMemcpyHostToDevice, sh.stream));
-        HIP_CHECK(hipMemcpyAsync((char*)dExcl + offBytes, pairs.data(), pairs.size() * sizeof(uint2), hipMemcpyHostToDevice, sh.stream));
-        dOff = (const uint32_t*)dExcl;
-        dPairs = (const uint2*)((char*)dExcl + offBytes);
+        char* D = (char*)dExcl;
+        if (!pairsT.empty()) {
+          HIP_CHECK(hipMemcpyAsync(D, offT.data(), (size_t)(K + 1) * 4, hipMemcpyHostToDevice, sh.stream));
+          HIP_CHECK(hipMemcpyAsync(D + oPT, pairsT.data(), pairsT.size() * sizeof(uint2), hipMemcpyHostToDevice, sh.stream));
+          dOffT = (const uint32_t*)D;
+          dPairsT = (const uint2*)(D + oPT);
+        }
+        if (!pairsS.empty()) {
+          HIP_CHECK(hipMemcpyAsync(D + offBytes, offS.data(), (size_t)(K + 1) * 4, hipMemcpyHostToDevice, sh.stream));
+          HIP_CHECK(hipMemcpyAsync(D + oPS, pairsS.data(), pairsS.size() * sizeof(uint2), hipMemcpyHostToDevice, sh.stream));
+          HIP_CHECK(hipMemcpyAsync(D + oTS, tS.data(), tS.size() * 4, hipMemcpyHostToDevice, sh.stream));
+          dOffS = (const uint32_t*)(D + offBytes);
+          dPairsS = (const uint2*)(D + oPS);
+          dTS = (const uint32_t*)(D + oTS);
+        }
       }
       HIP_CHECK(hipMemcpyAsync(sh.stageDev, h, bytes, hipMemcpyHostToDevice, sh.stream));
-      launch_on(s, s->triAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr, dOff, dPairs);
-      launch_on(s, s->subdivAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr);
+      launch_on(s, s->triAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr, dOffT, dPairsT);
+      if (!(occluded && forkAccel))
+        launch_on(s, s->subdivAccel, 0, sh.stageDev, K, (uint32_t)sizeof(RTCRayHit), false, instID, nullptr, dOffS, dPairsS, nullptr, false, dTS);
       HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
       HIP_CHECK(hipStreamSynchronize(sh.stream));
       next.clear();
@@ -217,12 +264,15 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
         if (!found) continue; // miss: the caller's record stays as it is
         // the hit reports instID in geomID when instanced; instancing is not on this path, so geomID is the geometry
         Geometry* geo = got.hit.geomID < s->geometries.size() ? s->geometries[got.hit.geomID] : nullptr;
-        RTCFilterFunctionN fn = geo ? (occluded ? geo->occludedFilter : geo->intersectFilter) : nullptr;
+        const bool onSubdiv = geo && geo->type == RTC_GEOMETRY_TYPE_SUBDIVISION;
+        const bool unfiltered = onSubdiv && forkAccel;
+        RTCFilterFunctionN fn = geo && !unfiltered ? (occluded ? geo->occludedFilter : geo->intersectFilter) : nullptr;
+        RTCFilterFunctionN cfn = unfiltered ? nullptr : ctx->filter;
         bool accepted = true;
         RTCRayHit cand = W[i];
         cand.ray.tfar = got.ray.tfar; // filter.h / intersector_epilog.h:277-279: the callback sees tfar = candidate distance
         RTCHit hit = got.hit;
-        if (fn || ctx->filter) {
+        if (fn || cfn) {
           int mask = -1;
           RTCFilterFunctionNArguments a;
           a.valid = &mask;
@@ -232,14 +282,16 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
           a.hit = (RTCHitN*)&hit;
           a.N = 1;
           if (fn) fn(&a);
-          if (mask != 0 && ctx->filter) ctx->filter(&a);
+          if (mask != 0 && cfn) cfn(&a);
           accepted = mask != 0;
         }
         if (accepted) {
           if (occluded) W[i].ray.tfar = -std::numeric_limits<float>::infinity();
           else { W[i].ray = cand.ray; W[i].hit = hit; } // copyHitToRay
         } else {
-          excl[i].push_back(make_uint2(got.hit.geomID, got.hit.primID));
+          uint32_t tb;
+          memcpy(&tb, &got.ray.tfar, 4);
+          (onSubdiv ? exclSub : exclTri)[i].push_back(Rejected{got.hit.geomID, got.hit.primID, tb});
           next.push_back(i);
         }
       }
@@ -271,7 +323,9 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   dev->useDevice();
   if (byteStride > 0xFFFFFFFFull) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "byteStride too large");
   if (((uintptr_t)rays) & 3) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "ray not aligned to 4 bytes"); // rtcore.cpp:413
-  if (!countersOut && ((ctx && ctx->filter) || s->subdivFilter || (occluded ? s->triOccludedFilter : s->triIntersectFilter))) {
+  // (geometry filters on subdivision meshes are called on the eager accel only: the fork's intersector never calls one, see trace_filtered)
+  const bool subdivFilters = s->subdivFilter && s->subdivAccel.kind == ACCEL_GRIDSOA;
+  if (!countersOut && ((ctx && ctx->filter) || subdivFilters || (occluded ? s->triOccludedFilter : s->triIntersectFilter))) {
     trace_filtered(s, rays, M, byteStride, occluded, ctx);
     return;
   }

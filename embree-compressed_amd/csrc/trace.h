@@ -32,8 +32,11 @@ struct LaunchParams
   // Filter-function re-trace (row f3): ray i skips the triangles (geomID, primID) listed in
   // exclPairs[exclOffsets[i] .. exclOffsets[i+1]) - the candidates a host filter callback rejected in earlier rounds.
   // nullptr for ordinary launches.
+  // Grid cells (eager subdivision path): the triangles of a patch share (geomID, primID), so an entry also carries the candidate's
+  // distance, exclT[e] = bits of t - the kernels are deterministic, the same triangle yields the same t on the re-trace.
   const uint32_t* exclOffsets;
   const uint2* exclPairs;
+  const uint32_t* exclT;
   uint32_t poolKernel;     // 1: ray-pool skeleton (trace_pool.hip.h), 0: lane-per-ray skeleton (trace_loop.hip.h)
   // Root cull pass (trace_cull.hip.h): when `survivors` is set, a streaming pre-pass has tested every ray against the root node's
   // children and appended the indices of the rays that hit at least one of them to per-work-queue lists: queue q's list starts

@@ -68,6 +68,19 @@ __device__ __forceinline__ bool pluecker_rel(const RayState& r, const RelV a, co
   return true;
 }
 
+// Filter re-trace (row f3, LaunchParams::exclOffsets): a triangle of patch (geomID, primID) whose distance is bit-equal to one the
+// host filter rejected for this ray in an earlier round stays rejected (Intersect1EpilogMU offers the candidates of a cell one by
+// one, intersector_epilog.h:488-509; here the host does, between passes).
+__device__ __forceinline__ bool cell_candidate_excluded(const LaunchParams& P, uint32_t rayIdx, uint32_t geomID, uint32_t primID, float t)
+{
+  const uint32_t e1 = P.exclOffsets[rayIdx + 1];
+  for (uint32_t e = P.exclOffsets[rayIdx]; e < e1; e++) {
+    const uint2 q = P.exclPairs[e];
+    if (q.x == geomID && q.y == primID && P.exclT[e] == __float_as_uint(t)) return true;
+  }
+  return false;
+}
+
 struct GridCellLeaf
 {
   static constexpr bool OCTET = true;
@@ -99,7 +112,8 @@ struct GridCellLeaf
     const RelV c = RelV{gp[i2] - r.ox, gp[9u + i2] - r.oy, gp[18u + i2] - r.oz};
     TriHit h;
     h.t = RT_INF;
-    const bool ok = pluecker_rel(r, a, b, c, r.tfar, h) && valid;
+    bool ok = pluecker_rel(r, a, b, c, r.tfar, h) && valid;
+    if (ok && P.exclOffsets) ok = !cell_candidate_excluded(P, __float_as_uint(x[10]), __float_as_uint(gp[36]), __float_as_uint(gp[37]), h.t);
     const uint32_t mask8 = (uint32_t)(__ballot(ok) >> (lid & 56u)) & 0xffu;
     if (COUNT && valid && k == 0u) {
       wc.prims++;
@@ -133,7 +147,7 @@ struct GridCellLeaf
   }
 
   template <bool OCCLUDED, bool COUNT>
-  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t)
+  static __device__ __forceinline__ bool intersect(const LaunchParams& P, uint32_t ref, RayState& r, WorkCounters& wc, uint32_t rayIdx)
   {
     const uint32_t idx = ref & 0x7FFFFFFFu;
     const float4* gp = (const float4*)(P.accel.blobs + (size_t)idx * sizeof(GridCell));
@@ -162,6 +176,7 @@ struct GridCellLeaf
       if (COUNT) wc.inner++;
       TriHit h;
       if (pluecker_rel(r, p[T0[l]], p[T1[l]], p[T2[l]], tfarBlock, h)) {
+        if (P.exclOffsets && cell_candidate_excluded(P, rayIdx, __float_as_uint(f[36]), __float_as_uint(f[37]), h.t)) continue;
         if (OCCLUDED) return true;
         if (!found || h.t < best.t) { // select_min: lowest lane among equal minima
           best = h;
