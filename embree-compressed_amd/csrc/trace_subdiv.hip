@@ -220,6 +220,9 @@ struct GridCellLeaf
 // their four child boxes as floats (96 B, plane-major: lx[4] ux[4] ly[4] uy[4] lz[4] uz[4]) instead of a 4-byte code of planes
 // relative to the parent box - nothing to decode and nothing inherited from the parent, so a descent carries only the node index.
 enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2, MODE_FULL = 3 };
+#ifndef TRACE_CBVH_PREFETCH
+#define TRACE_CBVH_PREFETCH 0 // measured r2 (profiles/r02_prefetch_and_priority_ab.txt): 2-3 % slower alone and in flight - the later lines are not what a blob visit waits for
+#endif
 
 // Node decode tables (compressed_node.h:488-510): border planes, mid planes, and their complements 1-x (the same
 // fp32 subtraction the reference performs per decode, done once).  They live in LDS: a lookup is one ds_read (~100
@@ -752,6 +755,10 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
   static constexpr bool CONST_NG = true; // dummy normal (1,0,0): written at store time by the lane kernel
   static constexpr bool HIT_IN_MEMORY = QUAD; // quad form: a hit is written to the ray record when it is found; only tfar stays in registers
   static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
+  // bytes of a blob of this mode and level (cbvh_blob_bytes, cbvh_encode.cpp)
+  static constexpr uint32_t BLOB_RAW = CBVH_HEADER_BYTES + CbvhGeom<LEVELS>::ELEMS * (MODE == MODE_FULL ? CBVH_FULL_NODE_BYTES : 4u) +
+                                       (MODE == MODE_LEAF ? 2u << (2 * LEVELS) : 0u);
+  static constexpr uint32_t BLOB_BYTES = ((MODE == MODE_GRID ? ((BLOB_RAW + 3u) & ~3u) + 12u * ((1u << LEVELS) + 1u) * ((1u << LEVELS) + 1u) : BLOB_RAW) + 15u) & ~15u;
 
   // Quad form of intersect() below for the ray in exchange row `x` (words 0..7 = org, tnear, dir, tfar; word 8 = leaf ref); lane
   // q of the quad `lid >> 2`.  On a hit lane 0 of the quad writes tfar, u, v, geomID, primID into words 0, 4..7 and sets word 9.
@@ -767,6 +774,12 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     const uint32_t idx = __float_as_uint(x[8]) & 0x7FFFFFFFu;
     const CbvhHeader* H = (const CbvhHeader*)(P.accel.blobs + (size_t)idx * P.accel.blobStride);
     if (COUNT && q == 0u) wc.prims++;
+#if TRACE_CBVH_PREFETCH
+    // The header fills the first two 128-byte lines of a blob; the deeper nodes and the cells lie in the next ones, and the walk
+    // would meet each of them as a separate dependent miss.  Their first touch is issued here, together with the header's.
+    uint32_t pf = 0u;
+    if (!OCCLUDED) pf = ((const uint32_t*)H)[min(64u + 32u * (q & 1u), BLOB_BYTES / 4u - 1u)];
+#endif
     if (OCCLUDED) { // the fork's occluded() stub (compressed.h:754-756): see intersect() below
       const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx, zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy, zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
       const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
@@ -809,6 +822,9 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
       far = fminf(fminf(fmaxf(t1z, t2z), far1), far);
       if (!(near <= far && near1 == near1 && far1 == far1)) return;
     }
+#if TRACE_CBVH_PREFETCH
+    asm volatile("" ::"v"(pf)); // (loads return in order: this costs no wait beyond the header's)
+#endif
     c.near = near;
     // projected ray between entry and exit point (:470-508): lane 0 / 1 = x / y of the entry point, lane 2 / 3 = of the exit point
     float tx, ty, tz;

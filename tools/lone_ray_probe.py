@@ -26,6 +26,14 @@ print('one wave, 64 copies: %d iterations, %d leaf phases, %.0f cycles total = %
     c['iterations'], c['leafPhases'], tot, tot / c['iterations'], c['nodeVisits'] // 64, c['primTests'] // 64, c['innerVisits'] // 64))
 if c['cyclesNode']:
     print('phase cycles per iteration: fetch %.0f node %.0f leaf(per leaf phase) %.0f pop %.0f' % (c['cyclesFetch'] / c['iterations'], c['cyclesNode'] / c['iterations'], c['cyclesLeaf'] / max(c['leafPhases'], 1), c['cyclesPop'] / c['iterations']))
+# the same ray alone in its wave (1 copy) and as 8 copies: the drain's case - child-parallel node steps, quad-form blob walk
+for copies in (1, 8):
+    b = torch.from_numpy(np.repeat(rays[best:best + 1], copies, 0)).cuda()
+    c = sc.intersect1M_counted(b)
+    tot = max(c['cyclesTotal'], 1)
+    print('%d cop%s: %d iterations, %d leaf phases, %.0f cycles total = %.0f cycles per iteration' % (copies, 'y' if copies == 1 else 'ies', c['iterations'], c['leafPhases'], tot, tot / c['iterations']))
+    if c['cyclesNode']:
+        print('   phase cycles per iteration: fetch %.0f node %.0f leaf(per leaf phase) %.0f pop %.0f' % (c['cyclesFetch'] / c['iterations'], c['cyclesNode'] / c['iterations'], c['cyclesLeaf'] / max(c['leafPhases'], 1), c['cyclesPop'] / c['iterations']))
 # wall time of the single-wave kernel
 for _ in range(3): sc.intersect1M(torch.from_numpy(np.repeat(rays[best:best + 1], 64, 0)).cuda())
 dev.synchronize()

@@ -1,0 +1,32 @@
+#!/bin/bash
+# SQ counter passes (stall / latency picture) of one bench workload, one stream (development aid).
+# usage: tools/sq_passes.sh <workload> [bench args]   -> gpurun_out/sqp_<workload>/summary.txt
+#        SQP_SETS=mem tools/sq_passes.sh ...             -> the L1 / TLB / L2 / fabric picture instead of the SQ one
+W=$1; shift
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/sqp_$W
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+i=0
+if [ "$SQP_SETS" = mem ]; then
+  SETS=("TCP_TOTAL_ACCESSES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCP_LATENCY_sum"
+        "TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_GATE_EN2_sum"
+        "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_MULTI_MISS_sum"
+        "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum"
+        "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_sum"
+        "TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum")
+else
+  SETS=("SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"
+        "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM"
+        "SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
+        "SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA"
+        "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+        "SQ_WAVES SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU")
+fi
+for set in "${SETS[@]}"; do
+  i=$((i+1))
+  echo "== pass $i: $set" >> $O/summary.txt
+  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -- python3 $R/bench.py --workload $W "$@" --inflight 1 --steps 6 --warmup 2 --cpu-seconds 0 --no-others > $O/log_$i.txt 2>&1 || { echo "pass failed" >> $O/summary.txt; tail -n 3 $O/log_$i.txt >> $O/summary.txt; exit 1; }
+  python3 $R/tools/sq_summary.py $O/p$i >> $O/summary.txt
+done
+cat $O/summary.txt
