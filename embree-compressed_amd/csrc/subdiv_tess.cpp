@@ -804,9 +804,15 @@ void interpolate_triangles(const Geometry* geom, const RTCInterpolateArguments* 
 // The reference evaluates through patch classification, bicubic B-spline patches, feature-adaptive subdivision and
 // Gregory patches (scene_subdiv_mesh.cpp:757-864, patch_eval.h).  Here the buffer is refined K = 3 times with the
 // tessellator's refiner (per three channels); a sub-face all of whose corners are regular interior vertices is a uniform
-// bicubic B-spline patch over its 4x4 neighbourhood - the exact limit surface with exact derivatives; the remaining
-// sub-faces (touching an extraordinary vertex or the boundary: 1/64 of a face per such corner) are evaluated bilinearly
-// between the limit points of their corners, where the reference uses its own approximation (Gregory).
+// bicubic B-spline patch over its 4x4 neighbourhood - the exact limit surface with exact derivatives.  The remaining
+// sub-faces (touching an extraordinary vertex, a crease or the boundary: 1/64 of a face per such corner) are evaluated
+// FEATURE-ADAPTIVELY like the reference's FeatureAdaptiveEval (feature_adaptive_eval.h:130-140, patch.h:40-42): the
+// sub-face and its one-ring are cut out, refined once more, the quarter that contains (u,v) and ITS one-ring are cut out
+// again, and so on until that quarter is a regular B-spline patch or the reference's maximum depth of 10 levels below
+// the base face is reached (PATCH_MAX_EVAL_DEPTH_IRREGULAR / _CREASE); only there - a cell of 2^-10 of the face's side,
+// where the reference fills in a Gregory patch (PATCH_USE_GREGORY == 1: "fill") - the limit points of the cell's
+// corners are interpolated bilinearly.  (One-rings suffice: every point of a child cell's one-ring is a vertex, edge or
+// face point whose stencil lies inside the parent cell's one-ring.)
 struct InterpChannels
 {
   Level lvl;              // level-K values of three channels
@@ -815,6 +821,7 @@ struct InterpChannels
 struct SubdivInterpCache
 {
   unsigned n = 8; // sub-faces per base-face side (2^K)
+  RTCSubdivisionMode mode = RTC_SUBDIVISION_MODE_SMOOTH_BOUNDARY; // boundary rule of the geometry (the refiner's PIN_ALL edge rule needs it)
   bool mixed = false;             // the mesh has faces that are not quads: base faces are the sub-quads of one generic step
   std::vector<int> primToFace;    // primID -> first base face (-1: invalid face)
   std::vector<unsigned> primCorners; // primID -> number of corners
@@ -825,6 +832,7 @@ struct SubdivInterpCache
   std::mutex mutex;
 };
 static const unsigned INTERP_LEVELS = 3;
+static const unsigned INTERP_MAX_DEPTH = 10; // PATCH_MAX_EVAL_DEPTH_IRREGULAR / _CREASE (patch.h:40-41)
 
 static void refine_to_interp_level(Level& cur, RTCSubdivisionMode mode, bool first, std::vector<D3>* limit, std::vector<uint8_t>* irregular)
 {
@@ -858,6 +866,169 @@ static void cubic_bspline(double s, double B[4], double dB[4], double ddB[4])
   ddB[0] = r; ddB[1] = 3.0 * s - 2.0; ddB[2] = -3.0 * s + 1.0; ddB[3] = s;
 }
 
+// ---- local feature-adaptive evaluation (see the comment above SubdivInterpCache) ---------------------------------------
+struct MiniCell { uint32_t v[4]; }; // corners (0,0), (1,0), (1,1), (0,1) of a cell, ids of the level it was cut from
+
+// a level of single-quad faces (n = 1) made of `cells` (face k = cells[k]) with the per-vertex / per-edge state of `src`
+static void mini_from_cells(const Level& src, const std::vector<MiniCell>& cells, Level& out)
+{
+  out = Level();
+  out.n = 1;
+  std::unordered_map<uint32_t, uint32_t> id;
+  auto map_vertex = [&](uint32_t v) -> uint32_t {
+    auto it = id.find(v);
+    if (it != id.end()) return it->second;
+    const uint32_t k = (uint32_t)id.size();
+    id.emplace(v, k);
+    out.P.push_back(src.P[v]);
+    out.pinned.push_back(v < src.pinned.size() ? src.pinned[v] : 0);
+    out.bpin.push_back(v < src.bpin.size() ? src.bpin[v] : 0);
+    return k;
+  };
+  out.grid.reserve(cells.size());
+  for (const MiniCell& c : cells) {
+    const uint32_t a = map_vertex(c.v[0]), b = map_vertex(c.v[1]), cc = map_vertex(c.v[2]), d = map_vertex(c.v[3]);
+    out.grid.push_back({a, b, d, cc}); // row-major [j][i]
+  }
+  if (!src.vcrease.empty()) {
+    out.vcrease.assign(out.P.size(), 0.f);
+    for (auto& kv : id) out.vcrease[kv.second] = src.vertex_crease(kv.first);
+  }
+  if (!src.crease.empty())
+    for (const MiniCell& c : cells)
+      for (int k = 0; k < 4; k++) {
+        const uint32_t a = c.v[k], b = c.v[(k + 1) & 3];
+        auto it = src.crease.find(edge_key(a, b));
+        if (it != src.crease.end() && it->second > 0.f) out.crease[edge_key(id[a], id[b])] = it->second;
+      }
+}
+
+struct PatchValue { D3 P, Pu, Pv, Puu, Pvv, Puv; }; // derivatives w.r.t. the cell's own (s, t) in [0,1]^2
+
+static PatchValue eval_bspline16(const std::vector<D3>& P, const uint32_t C[4][4], double s, double t)
+{
+  double Bu[4], dBu[4], ddBu[4], Bv[4], dBv[4], ddBv[4];
+  cubic_bspline(s, Bu, dBu, ddBu);
+  cubic_bspline(t, Bv, dBv, ddBv);
+  PatchValue o;
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) {
+      const D3& cp = P[C[r][c]];
+      o.P += cp * (Bv[r] * Bu[c]);
+      o.Pu += cp * (Bv[r] * dBu[c]);
+      o.Pv += cp * (dBv[r] * Bu[c]);
+      o.Puu += cp * (Bv[r] * ddBu[c]);
+      o.Pvv += cp * (ddBv[r] * Bu[c]);
+      o.Puv += cp * (dBv[r] * dBu[c]);
+    }
+  return o;
+}
+
+static PatchValue eval_bilinear(const D3& L00, const D3& L10, const D3& L11, const D3& L01, double s, double t)
+{
+  PatchValue o;
+  o.P = L00 * ((1 - s) * (1 - t)) + L10 * (s * (1 - t)) + L01 * ((1 - s) * t) + L11 * (s * t);
+  o.Pu = (L10 - L00) * (1 - t) + (L11 - L01) * t;
+  o.Pv = (L01 - L00) * (1 - s) + (L11 - L10) * s;
+  o.Puv = (L11 - L10) - (L01 - L00);
+  return o;
+}
+
+// the 4x4 control net around face `self` of a level of single-quad faces, if all four corners are regular interior vertices
+static bool mini_regular_net(const Level& lv, const Refiner& R, uint32_t self, uint32_t C[4][4])
+{
+  auto corners = [&](uint32_t f, uint32_t out[4]) { const std::vector<uint32_t>& g = lv.grid[f]; out[0] = g[0]; out[1] = g[1]; out[2] = g[3]; out[3] = g[2]; };
+  uint32_t q[4];
+  corners(self, q);
+  for (int k = 0; k < 4; k++) {
+    const Acc& a = R.acc[q[k]];
+    if (a.nb != 0 || a.nf != 4 || a.ne != 4 || lv.pinned[q[k]] || R.creased(q[k])) return false;
+  }
+  const uint32_t nf = (uint32_t)lv.grid.size();
+  auto across = [&](uint32_t a, uint32_t b, uint32_t& oa, uint32_t& ob) -> int64_t { // the other face with edge (a,b); oa / ob: its vertices next to a / b
+    for (uint32_t f = 0; f < nf; f++) {
+      if (f == self) continue;
+      uint32_t v[4];
+      corners(f, v);
+      int ia = -1, ib = -1;
+      for (int m = 0; m < 4; m++) { if (v[m] == a) ia = m; if (v[m] == b) ib = m; }
+      if (ia < 0 || ib < 0) continue;
+      if ((ia + 1) % 4 == ib) { oa = v[(ia + 3) % 4]; ob = v[(ib + 1) % 4]; }
+      else if ((ib + 1) % 4 == ia) { oa = v[(ia + 1) % 4]; ob = v[(ib + 3) % 4]; }
+      else continue;
+      return f;
+    }
+    return -1;
+  };
+  auto diagonal = [&](uint32_t a, int64_t n1, int64_t n2, uint32_t& od) -> bool { // the fourth face around a: its vertex opposite a
+    for (uint32_t f = 0; f < nf; f++) {
+      if (f == self || (int64_t)f == n1 || (int64_t)f == n2) continue;
+      uint32_t v[4];
+      corners(f, v);
+      for (int m = 0; m < 4; m++)
+        if (v[m] == a) { od = v[(m + 2) % 4]; return true; }
+    }
+    return false;
+  };
+  const uint32_t c00 = q[0], c10 = q[1], c11 = q[2], c01 = q[3];
+  C[1][1] = c00; C[1][2] = c10; C[2][2] = c11; C[2][1] = c01;
+  const int64_t qb = across(c00, c10, C[0][1], C[0][2]);
+  const int64_t qr = across(c10, c11, C[1][3], C[2][3]);
+  const int64_t qt = across(c11, c01, C[3][2], C[3][1]);
+  const int64_t ql = across(c01, c00, C[2][0], C[1][0]);
+  return qb >= 0 && qr >= 0 && qt >= 0 && ql >= 0 && diagonal(c00, qb, ql, C[0][0]) && diagonal(c10, qb, qr, C[0][3]) &&
+         diagonal(c11, qr, qt, C[3][3]) && diagonal(c01, qt, ql, C[3][0]);
+}
+
+// Evaluates the cell ring[0] of level `lvK` (ring = the cell and every other cell that shares a vertex with it) at (s, t).
+// `depthOut` = number of refinements below lvK at which the value was taken (the derivatives are w.r.t. that cell's own
+// parameters: the caller scales them by 2^depth).
+static PatchValue adaptive_eval(const Level& lvK, RTCSubdivisionMode mode, const std::vector<MiniCell>& ring, double s, double t,
+                                unsigned maxDepth, unsigned& depthOut)
+{
+  Level mini;
+  mini_from_cells(lvK, ring, mini);
+  for (unsigned d = 0;; d++) {
+    Refiner R(mini, mode, false);
+    R.accumulate();
+    uint32_t C[4][4];
+    depthOut = d;
+    if (mini_regular_net(mini, R, 0u, C)) return eval_bspline16(mini.P, C, s, t);
+    const std::vector<uint32_t>& g = mini.grid[0];
+    if (d >= maxDepth)
+      return eval_bilinear(R.limit_point(g[0], mini.pinned), R.limit_point(g[1], mini.pinned), R.limit_point(g[3], mini.pinned),
+                           R.limit_point(g[2], mini.pinned), s, t);
+    Level next;
+    R.refine(next);
+    const unsigned ci = s >= 0.5 ? 1u : 0u, cj = t >= 0.5 ? 1u : 0u;
+    s = std::min(1.0, std::max(0.0, 2.0 * s - ci));
+    t = std::min(1.0, std::max(0.0, 2.0 * t - cj));
+    auto cell_of = [&](size_t f, unsigned i, unsigned j) {
+      const std::vector<uint32_t>& G = next.grid[f]; // 3 x 3
+      MiniCell c;
+      c.v[0] = G[j * 3 + i]; c.v[1] = G[j * 3 + i + 1]; c.v[2] = G[(j + 1) * 3 + i + 1]; c.v[3] = G[(j + 1) * 3 + i];
+      return c;
+    };
+    std::vector<MiniCell> cells;
+    const MiniCell child = cell_of(0, ci, cj);
+    cells.push_back(child);
+    for (size_t f = 0; f < next.grid.size(); f++)
+      for (unsigned j = 0; j < 2; j++)
+        for (unsigned i = 0; i < 2; i++) {
+          if (f == 0 && i == ci && j == cj) continue;
+          const MiniCell c = cell_of(f, i, j);
+          bool touches = false;
+          for (int a = 0; a < 4 && !touches; a++)
+            for (int b = 0; b < 4; b++)
+              if (c.v[a] == child.v[b]) { touches = true; break; }
+          if (touches) cells.push_back(c);
+        }
+    Level cut;
+    mini_from_cells(next, cells, cut);
+    mini = std::move(cut);
+  }
+}
+
 void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
 {
   if (args->bufferType != RTC_BUFFER_TYPE_VERTEX && args->bufferType != RTC_BUFFER_TYPE_VERTEX_ATTRIBUTE)
@@ -886,6 +1057,7 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
         dummy.assign(any->count, D3());
       }
       const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first, topo ? &dummy : nullptr, topo);
+      cache->mode = mode;
       cache->mixed = !first;
       const BufferView* fb = geom->view(RTC_BUFFER_TYPE_FACE, 0);
       cache->primToFace.assign(fb->count, -1);
@@ -1021,30 +1193,35 @@ void interpolate_subdiv(Geometry* geom, const RTCInterpolateArguments* args)
     regular = qb >= 0 && qr >= 0 && qt >= 0 && ql >= 0 && diagonal(c00, q, qb, ql, C[0][0]) && diagonal(c10, q, qb, qr, C[0][3]) &&
               diagonal(c11, q, qr, qt, C[3][3]) && diagonal(c01, q, qt, ql, C[3][0]);
   }
-  double Bu[4], dBu[4], ddBu[4], Bv[4], dBv[4], ddBv[4];
-  if (regular) { cubic_bspline(s, Bu, dBu, ddBu); cubic_bspline(t, Bv, dBv, ddBv); }
-  const double sc = (double)n;
+  // irregular cell: its one-ring (the cell first), for the feature-adaptive evaluation
+  std::vector<MiniCell> ring;
+  if (!regular) {
+    const uint32_t own[4] = {c00, c10, c11, c01};
+    MiniCell self;
+    for (int k = 0; k < 4; k++) self.v[k] = own[k];
+    ring.push_back(self);
+    std::vector<uint32_t> seen(1, q);
+    for (int k = 0; k < 4; k++)
+      for (uint32_t e = cache->vqStart[own[k]]; e < cache->vqStart[own[k] + 1]; e++) {
+        const uint32_t qq = cache->vqList[e];
+        if (std::find(seen.begin(), seen.end(), qq) != seen.end()) continue;
+        seen.push_back(qq);
+        MiniCell c;
+        quad_verts(qq, c.v);
+        ring.push_back(c);
+      }
+  }
+  double sc = (double)n;
   for (unsigned gi = 0; gi < groups; gi++) {
     const InterpChannels& ch = (*chans)[gi];
-    D3 P, Pu, Pv, Puu, Pvv, Puv;
-    if (regular) {
-      for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) {
-          const D3& cp = ch.lvl.P[C[r][c]];
-          P += cp * (Bv[r] * Bu[c]);
-          Pu += cp * (Bv[r] * dBu[c]);
-          Pv += cp * (dBv[r] * Bu[c]);
-          Puu += cp * (Bv[r] * ddBu[c]);
-          Pvv += cp * (ddBv[r] * Bu[c]);
-          Puv += cp * (dBv[r] * dBu[c]);
-        }
-    } else {
-      const D3 &L00 = ch.limit[c00], &L10 = ch.limit[c10], &L11 = ch.limit[c11], &L01 = ch.limit[c01];
-      P = L00 * ((1 - s) * (1 - t)) + L10 * (s * (1 - t)) + L01 * ((1 - s) * t) + L11 * (s * t);
-      Pu = (L10 - L00) * (1 - t) + (L11 - L01) * t;
-      Pv = (L01 - L00) * (1 - s) + (L11 - L10) * s;
-      Puv = (L11 - L10) - (L01 - L00);
+    PatchValue val;
+    if (regular) val = eval_bspline16(ch.lvl.P, C, s, t);
+    else {
+      unsigned depth = 0;
+      val = adaptive_eval(ch.lvl, cache->mode, ring, s, t, INTERP_MAX_DEPTH > INTERP_LEVELS ? INTERP_MAX_DEPTH - INTERP_LEVELS : 0u, depth);
+      sc = (double)n * (double)(1u << depth);
     }
+    const D3 &P = val.P, &Pu = val.Pu, &Pv = val.Pv, &Puu = val.Puu, &Pvv = val.Pvv, &Puv = val.Puv;
     // derivatives w.r.t. the base face's (ls, lt), then the chain rule to the caller's (u, v) (the map is affine)
     const D3 Ds = Pu * sc, Dt = Pv * sc, Dss = Puu * (sc * sc), Dtt = Pvv * (sc * sc), Dst = Puv * (sc * sc);
     const D3 Du = Ds * jsu + Dt * jtu, Dv = Ds * jsv + Dt * jtv;

@@ -165,3 +165,53 @@ def test_face_varying_attribute_topology(rtc):
     sc.release()
     sc2.release()
     dev.release()
+
+
+def test_subdiv_interpolation_next_to_extraordinary_vertices_is_feature_adaptive(rtc):
+    """rtcInterpolate inside the cells that touch an extraordinary vertex: the reference subdivides such a patch adaptively
+    down to depth 10 and evaluates regular B-spline sub-patches (feature_adaptive_eval.h:130-140, patch.h:40-42); only the
+    last 2^-10 of the parameter range next to the vertex is a Gregory fill.  Checked against an INDEPENDENT numpy
+    Catmull-Clark refinement (tests/test_host_ngons.py) of a cube (eight valence-3 vertices) and of a mesh with a valence-5
+    vertex: following the corner child of a face for L steps gives the exact limit points of the surface at (0,0), (h,0),
+    (h,h), (0,h), h = 2^-L - for L >= 4 these lie strictly inside the level-3 cell at the extraordinary corner, where a
+    bilinear blend of the cell's corner limit points (the round-1 evaluation) is off by percents of the face size.
+    Parity with the reference itself stays unpinned (no reference-held vector)."""
+    from test_host_creases import CUBE_F, CUBE_V
+    from test_host_ngons import _cc_step, _limit
+
+    # valence 5: five quads around vertex 0, closed at the back by a second fan (double pyramid over a pentagon ring)
+    ang = np.linspace(0, 2 * np.pi, 6)[:-1]
+    ring = np.stack([np.cos(ang), np.sin(ang), 0 * ang], 1)
+    mid = np.stack([np.cos(ang + np.pi / 5), np.sin(ang + np.pi / 5), 0 * ang], 1) * 1.3
+    V5 = np.concatenate([[[0, 0, 1.0]], ring * 0.7 + [0, 0, 0.5], mid, [[0, 0, -1.0]]]).astype(np.float32)
+    F5 = [(0, 1 + k, 6 + k, 1 + (k + 1) % 5) for k in range(5)] + [(11, 1 + (k + 1) % 5, 6 + k, 1 + k) for k in range(5)]
+
+    for name, V, F in (("cube", CUBE_V, CUBE_F), ("valence5", V5, F5)):
+        dev = rtc.Device("gpu=none")
+        sc = rtc.Scene(dev)
+        gid = sc.add_subdiv(V, np.full(len(F), 4, np.uint32), np.array(F, np.uint32).ravel())
+        sc.commit()
+        scale = float(np.abs(V).max())
+        for face in (0, len(F) - 1):
+            Vl, Q = np.asarray(V, np.float64), [tuple(f) for f in F]
+            fi = face
+            worst_old_style = 0.0
+            for L in range(1, 7):
+                Vl, Q = _cc_step(Vl, Q)
+                fi = 4 * fi  # corner child at the face's first vertex: (v0, E01, F, E30), same (u, v) orientation
+                h = 2.0 ** -L
+                q = Q[fi]
+                for (u, v), vid in (((0.0, 0.0), q[0]), ((h, 0.0), q[1]), ((h, h), q[2]), ((0.0, h), q[3])):
+                    want = _limit(Vl, Q, vid)
+                    got = sc.interpolate(gid, face, u, v, derivs=0)[0].astype(np.float64)
+                    assert np.abs(got - want).max() < 3e-6 * scale, (name, face, L, u, v, got, want)
+            # derivatives inside the extraordinary cell agree with central differences of the surface itself
+            for (u, v) in ((0.03, 0.02), (0.06, 0.09), (0.004, 0.11), (0.0007, 0.0004)):
+                P, du, dv = sc.interpolate(gid, face, u, v, derivs=1)[:3]
+                e = 1e-4 * min(1.0, 50 * max(u, v))
+                fdu = (sc.interpolate(gid, face, u + e, v, derivs=0)[0].astype(np.float64) - sc.interpolate(gid, face, max(u - e, 0.0), v, derivs=0)[0]) / (u + e - max(u - e, 0.0))
+                fdv = (sc.interpolate(gid, face, u, v + e, derivs=0)[0].astype(np.float64) - sc.interpolate(gid, face, u, max(v - e, 0.0), derivs=0)[0]) / (v + e - max(v - e, 0.0))
+                assert np.abs(du - fdu).max() < 2e-2 * max(1.0, np.abs(fdu).max()), (name, face, u, v, du, fdu)
+                assert np.abs(dv - fdv).max() < 2e-2 * max(1.0, np.abs(fdv).max()), (name, face, u, v, dv, fdv)
+        sc.release()
+        dev.release()
