@@ -356,8 +356,9 @@ def main():
         }
         if world == 1 and args.rays_kind == "random" and not occluded:
             out["config"]["pcie_inclusive_Mrays"] = pcie_inclusive(sc, raygen, D, m, lo, hi, rank)
-            out["config"]["pcie_inclusive_note"] = ("one rtcIntersect1M call on pageable HOST records (staging + H2D + traversal + D2H + scatter), best of 3; "
-                                                    "`value` is the device-resident rate")
+            out["config"]["pcie_inclusive_note"] = ("one rtcIntersect1M call on pageable HOST records, best of 3: chunked pipeline of gather into pinned memory "
+                                                    "(host thread pool) / H2D / traversal / D2H on two alternating streams / scatter of tfar + hit "
+                                                    "(rt_trace.cpp trace_host_pipelined); `value` is the device-resident rate")
     if world == 1 and args.cpu_seconds > 0:
         out["cpu_baseline"] = cpu_baseline(sc, rtc, args.workload, mesh, levels, lo, hi, m, args.cpu_seconds)
     sc.release()

@@ -77,6 +77,9 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_OCT_STEPS")) tuneOctSteps = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_BUSY_BLOCKS")) tuneBusyBlocksOct = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_ALONE_BLOCKS")) tuneAloneBlocksOct = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_HOST_THREADS")) tuneHostThreads = (uint32_t)std::max(0, atoi(env));
+  if (const char* env = getenv("RTAMD_PIPE_MIN")) tunePipeMinRays = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_PIPE_CHUNK")) tunePipeChunk = (uint32_t)std::max(64, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_MAX")) tuneOctMax = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_KERNEL")) tunePoolKernel = strcmp(env, "pool") == 0 ? 1u : (strcmp(env, "lane") == 0 ? 0u : 2u);
   if (const char* env = getenv("RTAMD_BLOCKS_PER_CU")) { tuneBlocksPerCU = (uint32_t)std::max(0, atoi(env)); tuneBlocksAuto = false; }
@@ -102,6 +105,7 @@ Device::Device(const char* cfg)
     sh->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_CHECK(hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking));
     sh->ownsStream = true;
+    for (hipStream_t& ps : sh->pipeStream) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
     HIP_CHECK(hipMalloc(&sh->countersDev, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord)));
     HIP_CHECK(hipHostMalloc((void**)&sh->overflowHost, 64, hipHostMallocMapped));
     *sh->overflowHost = 0u;
@@ -127,6 +131,9 @@ Device::~Device()
       hipStreamSynchronize(sh.stream);
       hipStreamDestroy(sh.stream);
     }
+    for (hipStream_t ps : sh.pipeStream)
+      if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
+    for (hipEvent_t e : sh.pipeEvents) hipEventDestroy(e);
     if (sh.stageHost) hipHostFree(sh.stageHost);
     if (sh.stageDev) hipFree(sh.stageDev);
     for (LaunchCtx& c : sh.launchCtx) {
@@ -222,8 +229,9 @@ void Device::GpuShard::ensureStaging(size_t bytes)
   stageBytes = want;
 }
 
-Device::LaunchCtx& Device::GpuShard::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther)
+Device::LaunchCtx& Device::GpuShard::acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther, hipStream_t onStream)
 {
+  hipStream_t stream = onStream ? onStream : this->stream; // the stream the launch goes to
   unsigned others = 0;
   hipStream_t otherStreams[NUM_LAUNCH_CTX];
   // first context whose last kernel has finished (back-to-back batches on one stream then cycle through two or three
@@ -261,6 +269,58 @@ Device::LaunchCtx& Device::GpuShard::acquireLaunchCtx(size_t spillBytesNeeded, u
   c.used = true;
   c.stream = stream;
   return c;
+}
+
+// ---- HostPool ----------------------------------------------------------------------------------------
+void Device::HostPool::start(unsigned n)
+{
+  std::lock_guard<std::mutex> g(m);
+  while (threads.size() < n)
+    threads.emplace_back([this] {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cvWork.wait(lk, [this] { return stop || (job && nextPart < nParts); });
+        if (stop) return;
+        const size_t i = nextPart++;
+        inProgress++;
+        const std::function<void(size_t)>* f = job;
+        lk.unlock();
+        (*f)(i);
+        lk.lock();
+        if (--inProgress == 0 && nextPart >= nParts) cvDone.notify_all();
+      }
+    });
+}
+
+void Device::HostPool::run(size_t parts, const std::function<void(size_t)>& f)
+{
+  if (parts == 0) return;
+  std::unique_lock<std::mutex> lk(m);
+  job = &f;
+  nParts = parts;
+  nextPart = 0;
+  if (parts > 1 && !threads.empty()) cvWork.notify_all();
+  while (nextPart < nParts) { // the caller takes parts too
+    const size_t i = nextPart++;
+    inProgress++;
+    lk.unlock();
+    f(i);
+    lk.lock();
+    inProgress--;
+  }
+  cvDone.wait(lk, [this] { return inProgress == 0; });
+  job = nullptr;
+  nParts = nextPart = 0;
+}
+
+Device::HostPool::~HostPool()
+{
+  {
+    std::lock_guard<std::mutex> g(m);
+    stop = true;
+  }
+  cvWork.notify_all();
+  for (std::thread& t : threads) t.join();
 }
 
 // ---- Buffer ------------------------------------------------------------------------------------------

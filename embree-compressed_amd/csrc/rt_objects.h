@@ -6,7 +6,9 @@
 #include <memory>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 
 #include "accel.h"
@@ -65,6 +67,10 @@ struct Device : RefCounted
     void* stageHost = nullptr;
     void* stageDev = nullptr;
     size_t stageBytes = 0;
+    // pipelined host-pointer batches (rt_trace.cpp trace_host_pipelined): chunks alternate between two internal streams, so that
+    // the upload of one chunk runs under the traversal and the download of the previous one (PCIe is full duplex); one event per chunk
+    hipStream_t pipeStream[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> pipeEvents;
     // Per-launch scratch (work-queue heads + LDS-stack overflow area).  A ring of contexts, so that batches enqueued on
     // DIFFERENT streams (rtcamdSetDeviceStream between calls) can be in flight together: the drain of one batch - a few
     // deep rays keeping waves alive - then overlaps the start of the next.  A context is reused only after the kernel
@@ -84,13 +90,32 @@ struct Device : RefCounted
     void ensureStaging(size_t bytes);
     // picks the next context, makes `stream` wait for its previous user; *busyOther = OTHER streams with unfinished launches.
     // Call with seqMutex held.
-    LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther = nullptr);
+    LaunchCtx& acquireLaunchCtx(size_t spillBytesNeeded, unsigned* busyOther = nullptr, hipStream_t onStream = nullptr);
     void checkOverflow(); // throws RTC_ERROR_UNKNOWN (and clears the flag) when a kernel reported a dropped stack entry
   };
   std::vector<std::unique_ptr<GpuShard>> shards; // empty for gpu=none
   std::vector<int> gpuList;                      // "gpus=" ordinals in the order given
   GpuShard& primary() { return *shards[0]; }
   std::mutex launchMutex; // serialises host-pointer batches (they share the staging buffers) and counted batches
+
+  // Host threads for the staging copies of large host-pointer batches (gather of the caller's records into pinned memory, scatter of
+  // tfar + hit back): one thread moves ~10 GB/s, PCIe 5 x16 ~55 GB/s each way.  Started with the first such batch; the caller works too.
+  struct HostPool
+  {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cvWork, cvDone;
+    const std::function<void(size_t)>* job = nullptr;
+    size_t nParts = 0, nextPart = 0, inProgress = 0;
+    bool stop = false;
+    void start(unsigned n);
+    void run(size_t parts, const std::function<void(size_t)>& f); // f(0..parts-1), returns when all are done
+    ~HostPool();
+  };
+  HostPool hostPool;
+  uint32_t tuneHostThreads = 0;        // env RTAMD_HOST_THREADS (0: min(8, hardware threads / 2))
+  uint32_t tunePipeMinRays = 262144;   // env RTAMD_PIPE_MIN: host-pointer batches from this size on are pipelined in chunks
+  uint32_t tunePipeChunk = 131072;     // env RTAMD_PIPE_CHUNK: rays per chunk
 
   // Call combiner for small host-pointer calls (rtcIntersect1 / rtcOccluded1 / short 1M streams from many threads):
   // whoever finds the device idle becomes the leader and traces everything that is pending - its own call and the

@@ -32,7 +32,7 @@ static bool is_device_pointer(const void* p) { return pointer_device(p) >= 0; }
 // after the kernels (word 1 of a queue = rays that survived the root cull pre-pass, word 2 = valid rays the pre-pass tested)
 static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t M, uint32_t stride, bool occluded, uint32_t instID,
                       WaveRecord* dCounters, const uint32_t* exclOffsets = nullptr, const uint2* exclPairs = nullptr, uint32_t* cullCountsOut = nullptr,
-                      bool coherent = false, const uint32_t* exclT = nullptr)
+                      bool coherent = false, const uint32_t* exclT = nullptr, hipStream_t onStream = nullptr)
 {
   Device* dev = s->device;
   Device::GpuShard& sh = *dev->shards[si];
@@ -79,9 +79,9 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   // {context, queue heads, launch, event} as one unit: concurrent callers on device-resident batches must not pick the same
   // context (its event still reads "finished" until the new launch has recorded it).  The stream is read once.
   std::lock_guard<std::mutex> seq(sh.seqMutex);
-  const hipStream_t stream = sh.stream;
+  const hipStream_t stream = onStream ? onStream : sh.stream;
   unsigned busyOther = 0;
-  Device::LaunchCtx& ctx = sh.acquireLaunchCtx(spillBytes, &busyOther);
+  Device::LaunchCtx& ctx = sh.acquireLaunchCtx(spillBytes, &busyOther, stream);
   p.spill = ctx.spill;
   // A batch alone on the chip is fastest with two workgroups per CU; when two or more batches are running on other
   // streams a leaner grid is better: every wave pays its deepest ray's iterations, so fewer waves per batch waste fewer
@@ -314,6 +314,95 @@ static void trace_filtered(Scene* s, void* rays, uint32_t M, size_t byteStride, 
   }
 }
 
+// ---- large host-pointer batches: chunked pipeline ---------------------------------------------------------------------------
+// The callers of the drop-in API pass HOST records (viewer_stream_device.cpp:288-341).  One such batch used to be: memcpy into
+// pinned memory, H2D, traversal, D2H, scatter - one after the other, the copies on one host thread (~0.1 Grays/s; the traversal is
+// 1-2 % of that).  Here the range of every shard is cut into chunks of Device::tunePipeChunk rays; chunk k is gathered into pinned
+// memory by the host pool while chunks k-1 and k-2 are on the GPU (upload, traversal, download on two alternating internal streams:
+// PCIe is full duplex), and chunk k-2 is scattered back when its event has fired.  The results are those of the unpipelined path:
+// a stream is M independent rays (tests/test_gpu_host_pipeline.py compares the two byte for byte).
+static void trace_host_pipelined(Scene* s, char* rays, uint32_t M, size_t byteStride, bool occluded, uint32_t instID, bool coherent, uint32_t rec)
+{
+  Device* dev = s->device;
+  const size_t G = M < 2u * dev->shards.size() ? 1 : dev->shards.size();
+  const uint32_t CH = dev->tunePipeChunk;
+  const unsigned LAG = 2;
+  if (dev->hostPool.threads.empty()) {
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    const unsigned want = dev->tuneHostThreads ? dev->tuneHostThreads : std::min(8u, hw / 2u);
+    if (want > 1) dev->hostPool.start(want - 1); // the calling thread is the last worker
+  }
+  const size_t workers = dev->hostPool.threads.size() + 1;
+  struct Lane { Device::GpuShard* sh; size_t g; uint32_t lo, n, chunks; };
+  std::vector<Lane> lanes;
+  uint32_t maxChunks = 0;
+  for (size_t g = 0; g < G; g++) {
+    Lane L;
+    L.sh = dev->shards[g].get();
+    L.g = g;
+    L.lo = (uint32_t)((uint64_t)M * g / G);
+    L.n = (uint32_t)((uint64_t)M * (g + 1) / G) - L.lo;
+    if (L.n == 0) continue;
+    L.chunks = (L.n + CH - 1) / CH;
+    maxChunks = std::max(maxChunks, L.chunks);
+    L.sh->use();
+    L.sh->ensureStaging((size_t)L.n * rec);
+    while (L.sh->pipeEvents.size() < L.chunks) {
+      hipEvent_t e;
+      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      L.sh->pipeEvents.push_back(e);
+    }
+    lanes.push_back(L);
+  }
+  // rays [a, b) of a lane, split over the workers
+  auto for_parts = [&](uint32_t a, uint32_t b, const std::function<void(uint32_t, uint32_t)>& body) {
+    const uint32_t n = b - a;
+    const size_t parts = std::min<size_t>(workers, std::max<uint32_t>(1u, n / 4096u));
+    dev->hostPool.run(parts, [&](size_t p) { body(a + (uint32_t)((uint64_t)n * p / parts), a + (uint32_t)((uint64_t)n * (p + 1) / parts)); });
+  };
+  for (uint32_t k = 0; k < maxChunks + LAG; k++) {
+    for (Lane& L : lanes) {
+      if (k >= L.chunks) continue;
+      const uint32_t a = k * CH, b = std::min(L.n, a + CH);
+      char* h = (char*)L.sh->stageHost;
+      const char* src = rays + (size_t)L.lo * byteStride;
+      for_parts(a, b, [&](uint32_t x, uint32_t y) {
+        if (byteStride == rec) memcpy(h + (size_t)x * rec, src + (size_t)x * rec, (size_t)(y - x) * rec);
+        else
+          for (uint32_t i = x; i < y; i++) memcpy(h + (size_t)i * rec, src + (size_t)i * byteStride, rec);
+      });
+      L.sh->use();
+      const hipStream_t st = L.sh->pipeStream[k & 1u];
+      char* d = (char*)L.sh->stageDev + (size_t)a * rec;
+      const size_t bytes = (size_t)(b - a) * rec;
+      HIP_CHECK(hipMemcpyAsync(d, h + (size_t)a * rec, bytes, hipMemcpyHostToDevice, st));
+      launch_on(s, s->triAccel, L.g, d, b - a, rec, occluded, instID, nullptr, nullptr, nullptr, nullptr, coherent, nullptr, st);
+      launch_on(s, s->subdivAccel, L.g, d, b - a, rec, occluded, instID, nullptr, nullptr, nullptr, nullptr, coherent, nullptr, st);
+      HIP_CHECK(hipMemcpyAsync(h + (size_t)a * rec, d, bytes, hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipEventRecord(L.sh->pipeEvents[k], st));
+    }
+    if (k < LAG) continue;
+    const uint32_t j = k - LAG;
+    for (Lane& L : lanes) {
+      if (j >= L.chunks) continue;
+      L.sh->use();
+      HIP_CHECK(hipEventSynchronize(L.sh->pipeEvents[j]));
+      const uint32_t a = j * CH, b = std::min(L.n, a + CH);
+      const char* h = (const char*)L.sh->stageHost;
+      char* dst0 = rays + (size_t)L.lo * byteStride;
+      for_parts(a, b, [&](uint32_t x, uint32_t y) { // only tfar (byte 32) and the hit record (bytes 48..79) are outputs
+        for (uint32_t i = x; i < y; i++) {
+          char* dst = dst0 + (size_t)i * byteStride;
+          const char* src = h + (size_t)i * rec;
+          memcpy(dst + 32, src + 32, 4);
+          if (!occluded) memcpy(dst + 48, src + 48, 32);
+        }
+      });
+    }
+  }
+  for (Lane& L : lanes) L.sh->checkOverflow();
+}
+
 void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx,
                  TraceCounters* countersOut)
 {
@@ -372,6 +461,10 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
     // [g*M/G, (g+1)*M/G), one per shard: H2D, traversal and D2H of the ranges run concurrently on the shards' own streams
     // and write disjoint slices of the caller's buffer (no exchange step, no collective).
     if (!countLock.owns_lock()) countLock.lock();
+    if (!countersOut && M >= dev->tunePipeMinRays) {
+      trace_host_pipelined(s, (char*)rays, M, byteStride, occluded, instID, coherent, rec);
+      return;
+    }
     const size_t G = (countersOut || M < 2u * dev->shards.size()) ? 1 : dev->shards.size();
     std::vector<uint32_t> lo(G + 1);
     for (size_t g = 0; g <= G; g++) lo[g] = (uint32_t)((uint64_t)M * g / G);
