@@ -70,9 +70,10 @@ def parse():
 
 
 def build_hash():
-    """sha256 over the library's sources as recorded by embree-compressed_amd/Makefile at build time."""
+    """sha256 over the library's DEVICE sources (*.hip, *.hip.h, accel.h, trace.h) as recorded by embree-compressed_amd/Makefile at
+    build time (lib/KERNEL_HASH): a change of host code does not make a kernel profile stale, a change of kernel code does."""
     try:
-        return open(os.path.join(ROOT, "embree-compressed_amd", "lib", "BUILD_HASH")).read().strip()
+        return open(os.path.join(ROOT, "embree-compressed_amd", "lib", "KERNEL_HASH")).read().strip()
     except OSError:
         return None
 

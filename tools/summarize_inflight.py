@@ -33,7 +33,7 @@ def main():
         last = t
     span = t1 - t0
     try:
-        bh = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "embree-compressed_amd", "lib", "BUILD_HASH")).read().strip()
+        bh = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "embree-compressed_amd", "lib", "KERNEL_HASH")).read().strip()
     except OSError:
         bh = None
     out = {"build_hash": bh, "kernel": name[:140], "launches": len(ev), "span_us": span / 1e3, "us_per_launch_of_span": span / 1e3 / len(ev),

@@ -27,7 +27,7 @@ def main():
                 r[0] = r[0][:160]
                 w.writerow(r)
     try:
-        bh = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "embree-compressed_amd", "lib", "BUILD_HASH")).read().strip()
+        bh = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "embree-compressed_amd", "lib", "KERNEL_HASH")).read().strip()
     except OSError:
         bh = None
     out = {"build_hash": bh,
