@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--levels", default="6,3", help="subdivision level, compression level")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-others", action="store_true", help="skip the short tri / eager side runs")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-record (PCIe-inclusive) side measurement: under a profiler its chunk launches would mix into the kernel statistics")
     ap.add_argument("--inflight", type=int, default=4,
                     help="ray batches in flight: step s is enqueued on HIP stream s %% inflight (1 = one stream, strictly back-to-back)")
     ap.add_argument("--query", default="intersect", choices=["intersect", "occluded"],
@@ -355,7 +356,7 @@ def main():
                          "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          "in_flight_profile": inflight_profile(args.workload) if (m == 1_000_000 and levels == (6, 3) and args.rays_kind == "random" and not occluded) else None},
         }
-        if world == 1 and args.rays_kind == "random" and not occluded:
+        if world == 1 and args.rays_kind == "random" and not occluded and not args.no_pcie:
             out["config"]["pcie_inclusive_Mrays"] = pcie_inclusive(sc, raygen, D, m, lo, hi, rank)
             out["config"]["pcie_inclusive_note"] = ("one rtcIntersect1M call on pageable HOST records, best of 3: chunked pipeline of gather into pinned memory "
                                                     "(host thread pool) / H2D / traversal / D2H on two alternating streams / scatter of tfar + hit "

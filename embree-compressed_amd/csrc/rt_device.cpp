@@ -105,7 +105,6 @@ Device::Device(const char* cfg)
     sh->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_CHECK(hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking));
     sh->ownsStream = true;
-    for (hipStream_t& ps : sh->pipeStream) HIP_CHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
     HIP_CHECK(hipMalloc(&sh->countersDev, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord)));
     HIP_CHECK(hipHostMalloc((void**)&sh->overflowHost, 64, hipHostMallocMapped));
     *sh->overflowHost = 0u;

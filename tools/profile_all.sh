@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for w in cbvh.leaf tri; do
   O=$R/gpurun_out/prof_$w
   rm -rf $O && mkdir -p $O
-  A="--workload $w --inflight 1 --cpu-seconds 0 --no-others --steps 20 --warmup 3"
+  A="--workload $w --inflight 1 --cpu-seconds 0 --no-others --no-pcie --steps 20 --warmup 3"
   echo "== $w: kernel trace"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py $A > $O/bench_trace.json 2> $O/trace.err
   echo "== $w: FETCH_SIZE"
@@ -26,7 +26,7 @@ for w in cbvh.leaf tri; do
     # the mode `value` is measured in: four batches in flight on four streams (kernel trace only: counter collection would
     # serialise the dispatches)
     echo "== $w: kernel trace, 4 batches in flight"
-    timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_if4 -- python3 $R/bench.py --workload $w --inflight 4 --cpu-seconds 0 --no-others --steps 40 --warmup 4 > $O/bench_if4.json 2> $O/if4.err
+    timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/trace_if4 -- python3 $R/bench.py --workload $w --inflight 4 --cpu-seconds 0 --no-others --no-pcie --steps 40 --warmup 4 > $O/bench_if4.json 2> $O/if4.err
     python3 $R/tools/summarize_inflight.py $O/trace_if4 ${P}_inflight.json 40
     cp $O/bench_if4.json ${P}_inflight_bench.json
   fi
