@@ -271,54 +271,77 @@ Device::LaunchCtx& Device::GpuShard::acquireLaunchCtx(size_t spillBytesNeeded, u
 }
 
 // ---- HostPool ----------------------------------------------------------------------------------------
+bool Device::HostPool::take(uint64_t gen, size_t n, size_t& i)
+{
+  uint64_t t = ticket.load(std::memory_order_acquire);
+  for (;;) {
+    if ((t >> 32) != (gen & 0xffffffffull) || (t & 0xffffffffull) >= n) return false;
+    if (ticket.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) { i = (size_t)(t & 0xffffffffull); return true; }
+  }
+}
+
 void Device::HostPool::start(unsigned n)
 {
-  std::lock_guard<std::mutex> g(m);
   while (threads.size() < n)
     threads.emplace_back([this] {
-      std::unique_lock<std::mutex> lk(m);
+      uint64_t seen = 0;
       for (;;) {
-        cvWork.wait(lk, [this] { return stop || (job && nextPart < nParts); });
-        if (stop) return;
-        const size_t i = nextPart++;
-        inProgress++;
-        const std::function<void(size_t)>* f = job;
-        lk.unlock();
-        (*f)(i);
-        lk.lock();
-        if (--inProgress == 0 && nextPart >= nParts) cvDone.notify_all();
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [this] { return stop.load() || hot.load(); });
+          if (stop.load()) return;
+        }
+        while (hot.load(std::memory_order_acquire)) {
+          const uint64_t g = ticket.load(std::memory_order_acquire) >> 32;
+          if (g == seen) { __builtin_ia32_pause(); continue; }
+          seen = g;
+          const std::function<void(size_t)>* f = job.load(std::memory_order_relaxed); // written before the ticket of generation g was published
+          const size_t n = nParts.load(std::memory_order_relaxed);
+          size_t i;
+          while (take(g, n, i)) {
+            (*f)(i);
+            done.fetch_add(1, std::memory_order_acq_rel);
+          }
+        }
       }
     });
 }
 
+void Device::HostPool::begin()
+{
+  {
+    std::lock_guard<std::mutex> g(m);
+    hot.store(true, std::memory_order_release);
+  }
+  cv.notify_all();
+}
+
+void Device::HostPool::end() { hot.store(false, std::memory_order_release); }
+
 void Device::HostPool::run(size_t parts, const std::function<void(size_t)>& f)
 {
   if (parts == 0) return;
-  std::unique_lock<std::mutex> lk(m);
-  job = &f;
-  nParts = parts;
-  nextPart = 0;
-  if (parts > 1 && !threads.empty()) cvWork.notify_all();
-  while (nextPart < nParts) { // the caller takes parts too
-    const size_t i = nextPart++;
-    inProgress++;
-    lk.unlock();
+  const uint64_t g = ((ticket.load(std::memory_order_relaxed) >> 32) + 1) & 0xffffffffull;
+  job.store(&f, std::memory_order_relaxed);
+  nParts.store(parts, std::memory_order_relaxed);
+  done.store(0, std::memory_order_relaxed);
+  ticket.store(g << 32, std::memory_order_release); // publishes job / nParts
+  size_t i;
+  while (take(g, parts, i)) {
     f(i);
-    lk.lock();
-    inProgress--;
+    done.fetch_add(1, std::memory_order_acq_rel);
   }
-  cvDone.wait(lk, [this] { return inProgress == 0; });
-  job = nullptr;
-  nParts = nextPart = 0;
+  while (done.load(std::memory_order_acquire) < parts) __builtin_ia32_pause();
 }
 
 Device::HostPool::~HostPool()
 {
   {
     std::lock_guard<std::mutex> g(m);
-    stop = true;
+    stop.store(true);
+    hot.store(false);
   }
-  cvWork.notify_all();
+  cv.notify_all();
   for (std::thread& t : threads) t.join();
 }
 

@@ -102,14 +102,22 @@ struct Device : RefCounted
   // tfar + hit back): one thread moves ~10 GB/s, PCIe 5 x16 ~55 GB/s each way.  Started with the first such batch; the caller works too.
   struct HostPool
   {
+    // While a pipelined batch is running (`hot`) the helpers spin on `ticket` instead of sleeping: a part of a chunk is ~100 us of
+    // copying, a condition-variable wake-up costs 20-50 us.  ticket = (job generation << 32) | next part: a helper that is late for
+    // a job sees another generation and takes nothing.
     std::vector<std::thread> threads;
     std::mutex m;
-    std::condition_variable cvWork, cvDone;
-    const std::function<void(size_t)>* job = nullptr;
-    size_t nParts = 0, nextPart = 0, inProgress = 0;
-    bool stop = false;
+    std::condition_variable cv;
+    std::atomic<bool> stop{false}, hot{false};
+    std::atomic<uint64_t> ticket{0};
+    std::atomic<size_t> done{0};
+    std::atomic<const std::function<void(size_t)>*> job{nullptr}; // (a helper that is late may read these while the next job is being
+    std::atomic<size_t> nParts{0};                                 //  set up: its generation check then fails and it takes nothing)
     void start(unsigned n);
-    void run(size_t parts, const std::function<void(size_t)>& f); // f(0..parts-1), returns when all are done
+    void begin();                                                  // helpers start polling
+    void end();                                                    // helpers go back to sleep
+    void run(size_t parts, const std::function<void(size_t)>& f); // f(0..parts-1), returns when all are done; the caller works too
+    bool take(uint64_t gen, size_t n, size_t& i);
     ~HostPool();
   };
   HostPool hostPool;
