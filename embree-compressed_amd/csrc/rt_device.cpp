@@ -77,6 +77,7 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_OCT_STEPS")) tuneOctSteps = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_BUSY_BLOCKS")) tuneBusyBlocksOct = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_ALONE_BLOCKS")) tuneAloneBlocksOct = (uint32_t)std::max(1, atoi(env));
+  if (const char* env = getenv("RTAMD_ZEROCOPY_MAX")) tuneZeroCopyMax = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_HOST_THREADS")) tuneHostThreads = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_PIPE_MIN")) tunePipeMinRays = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_PIPE_CHUNK")) tunePipeChunk = (uint32_t)std::max(64, atoi(env));

@@ -121,6 +121,7 @@ struct Device : RefCounted
     ~HostPool();
   };
   HostPool hostPool;
+  uint32_t tuneZeroCopyMax = 512;      // env RTAMD_ZEROCOPY_MAX: host batches up to this many rays are traced in place in pinned host memory (0 = never)
   uint32_t tuneHostThreads = 0;        // env RTAMD_HOST_THREADS (0: min(8, hardware threads / 2))
   uint32_t tunePipeMinRays = 262144;   // env RTAMD_PIPE_MIN: host-pointer batches from this size on are pipelined in chunks
   uint32_t tunePipeChunk = 131072;     // env RTAMD_PIPE_CHUNK: rays per chunk

@@ -500,16 +500,21 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
       if (byteStride == rec) memcpy(h, src, bytes);
       else
         for (uint32_t i = 0; i < n; i++) memcpy(h + (size_t)i * rec, src + (size_t)i * byteStride, rec);
-      HIP_CHECK(hipMemcpyAsync(sh.stageDev, h, bytes, hipMemcpyHostToDevice, sh.stream));
+      // Small batches (single rays and the combiner's groups, row f2): the kernels read and write the pinned staging buffer in place
+      // over PCIe - two copies and their DMA latency less per call; a few KB of rays cost nothing over the bus.
+      void* dRays = sh.stageDev;
+      const bool zeroCopy = !countersOut && n <= dev->tuneZeroCopyMax;
+      if (zeroCopy) HIP_CHECK(hipHostGetDevicePointer(&dRays, h, 0));
+      else HIP_CHECK(hipMemcpyAsync(sh.stageDev, h, bytes, hipMemcpyHostToDevice, sh.stream));
       if (countersOut) {
         countShard = g;
         dCounters = (WaveRecord*)sh.countersDev;
         dCounters2 = dCounters + WAVE_LOG_CAPACITY;
         HIP_CHECK(hipMemsetAsync(dCounters, 0, logBytes, sh.stream));
       }
-      launch_on(s, s->triAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters, nullptr, nullptr, cull1, coherent);
-      launch_on(s, s->subdivAccel, g, sh.stageDev, n, rec, occluded, instID, dCounters2, nullptr, nullptr, cull2, coherent);
-      HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
+      launch_on(s, s->triAccel, g, dRays, n, rec, occluded, instID, dCounters, nullptr, nullptr, cull1, coherent);
+      launch_on(s, s->subdivAccel, g, dRays, n, rec, occluded, instID, dCounters2, nullptr, nullptr, cull2, coherent);
+      if (!zeroCopy) HIP_CHECK(hipMemcpyAsync(h, sh.stageDev, bytes, hipMemcpyDeviceToHost, sh.stream));
     }
     for (size_t g = 0; g < G; g++) {
       Device::GpuShard& sh = *dev->shards[g];
