@@ -803,6 +803,30 @@ API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent
   cbvh_debug_leaf_codec(box, v, extent, bytesOut, extentEstimate);
 }
 
+API unsigned long long rtcamdDebugHostPoolSelfTest(RTCDevice h, unsigned int threads, unsigned int cycles, unsigned int jobs, unsigned int parts)
+{
+  CATCH_BEGIN
+  VERIFY(h);
+  Device* dev = D(h);
+  std::lock_guard<std::mutex> lock(dev->launchMutex); // the pool serves one caller at a time (host-pointer batches hold this mutex too)
+  if (threads > 1 && dev->hostPool.threads.size() < threads - 1) dev->hostPool.start(threads - 1);
+  unsigned long long good = 0;
+  std::vector<std::atomic<unsigned>> hits(parts);
+  for (unsigned c = 0; c < cycles; c++) {
+    dev->hostPool.begin();
+    for (unsigned j = 0; j < jobs; j++) {
+      for (auto& x : hits) x.store(0u);
+      const unsigned salt = c * 7919u + j;
+      dev->hostPool.run(parts, [&](size_t i) { hits[i].fetch_add(1u + ((unsigned)i ^ salt) * 2u); });
+      for (unsigned i = 0; i < parts; i++) good += hits[i].load() == 1u + (i ^ salt) * 2u ? 1u : 0u;
+    }
+    dev->hostPool.end();
+  }
+  return good;
+  CATCH_END(D(h))
+  return 0;
+}
+
 API unsigned int rtcamdGetAccelRoot(RTCScene h)
 {
   CATCH_BEGIN

@@ -177,6 +177,7 @@ def load_library(path=LIB_PATH):
         "rtcamdGetAccelData": (vp, [vp, u, C.POINTER(sz)]),
         "rtcamdGetAccelRoot": (u, [vp]),
         "rtcamdDebugCbvhLeafCodec": (None, [vp, vp, C.c_float, vp, C.POINTER(C.c_float)]),
+        "rtcamdDebugHostPoolSelfTest": (C.c_ulonglong, [vp, u, u, u, u]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -105,6 +105,10 @@ RTC_API const void* rtcamdGetAccelData(RTCScene scene, unsigned int kind, size_t
  * kernels/geometry/compressed_leaf.h:193-251) on caller-supplied inputs: box = lower xyz, upper xyz of the parent box,
  * v = the four corner vertices (12 floats).  Lets tests compare it with the reference header compiled in oracle/_ref. */
 RTC_API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate);
+/* Test hook: runs `jobs` parallel jobs of `parts` parts each through the device's pool of staging threads (the pool behind the
+ * chunked pipeline of large host-pointer batches; `threads` helpers are started if fewer exist), in `cycles` begin / end cycles,
+ * and returns the number of parts that ran exactly once with the right index.  Works on a gpu=none device: CPU-side coverage of the pool. */
+RTC_API unsigned long long rtcamdDebugHostPoolSelfTest(RTCDevice device, unsigned int threads, unsigned int cycles, unsigned int jobs, unsigned int parts);
 /* Root reference of the BVH8 (encoding documented in DESIGN.md / csrc/accel.h). */
 RTC_API unsigned int rtcamdGetAccelRoot(RTCScene scene);
 

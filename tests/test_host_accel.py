@@ -199,3 +199,15 @@ def test_invalid_triangles_are_skipped(rtc):
     assert len(recs) == 1 and recs["primID"][0] == 0
     sc.release()
     dev.release()
+
+
+def test_host_pool_of_the_staging_pipeline(rtc):
+    """The pool of staging threads behind the chunked pipeline of large host-pointer batches (rt_device.cpp HostPool: helpers that
+    poll a ticket word while a batch runs, the caller works too) through its test hook on a gpu=none device: every part of every job
+    runs exactly once with its own index, over many begin / end cycles and with more helpers than this container has cores."""
+    dev = rtc.Device("gpu=none")
+    L = rtc.lib()
+    for threads, cycles, jobs, parts in ((1, 3, 50, 7), (4, 40, 60, 9), (12, 25, 80, 64), (4, 10, 200, 1)):
+        assert L.rtcamdDebugHostPoolSelfTest(dev.handle, threads, cycles, jobs, parts) == cycles * jobs * parts
+        assert dev.error() == 0
+    dev.release()
