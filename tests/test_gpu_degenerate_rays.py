@@ -129,3 +129,48 @@ def test_degenerate_rays_on_subdivision_accels(rtc, po, bomberman, accel):
     orc.free()
     sc.release()
     dev.release()
+
+
+@pytest.mark.parametrize("cfg", ["tri_accel=bvh8.triangle4v", "subdiv_accel=default", "subdiv_accel=bvh4.compressed.leaf"])
+def test_invalid_rays_terminate_and_leave_the_others_alone(rtc, po, bomberman, cfg):
+    """NaN / infinite origins, directions and intervals are outside the API (a renderer still produces one now and then): such a ray
+    must come back - it may visit the whole tree when every comparison of its slab tests is decided by the NaN rules - and must not
+    change the result of any other ray of the batch.  (What it reports itself is not checked: x86 max/min and IEEE maxNum treat
+    NaN differently, the reference defines nothing here.)"""
+    verts, fs, fi = bomberman
+    dev = rtc.Device(cfg)
+    sc = rtc.Scene(dev)
+    if cfg.startswith("tri"):
+        sc.add_triangles(verts, rtc.fan_triangulate(fs, fi))
+    else:
+        sc.add_subdiv(verts, fs, fi)
+        sc.set_levels(4, 2)
+    sc.commit()
+    lo, hi = verts.min(0), verts.max(0)
+    n = 40_000
+    clean = po.make_random_rays(n, lo, hi, seed=91)
+    want = clean.copy()
+    sc.intersect1M(want)
+    dirty = clean.copy()
+    bad = np.arange(100, n, 4001)  # ten rays
+    fields = ["org_x", "dir_y", "tnear", "tfar", "dir_z", "org_z"]
+    values = [np.nan, np.nan, np.nan, np.nan, np.inf, -np.inf]
+    for k, i in enumerate(bad):
+        dirty[fields[k % 6]][i] = values[k % 6]
+    dirty["dir_x"][bad[-1]] = dirty["dir_y"][bad[-1]] = dirty["dir_z"][bad[-1]] = 0.0  # null direction
+    sc.intersect1M(dirty)
+    keep = np.ones(n, bool)
+    keep[bad] = False
+    assert dirty[keep].tobytes() == want[keep].tobytes()
+    occ = rtc.aligned_rays(n)
+    for f in occ.dtype.names:
+        occ[f] = clean[f]
+    wocc = occ.copy()
+    sc.occluded1M(wocc)
+    for k, i in enumerate(bad):
+        occ[fields[k % 6]][i] = values[k % 6]
+    sc.occluded1M(occ)
+    assert occ[keep].tobytes() == wocc[keep].tobytes()
+    assert dev.error() == 0
+    sc.release()
+    dev.release()
