@@ -99,6 +99,22 @@ def pmc_traffic(kernel_tag, workload):
     return None, None
 
 
+def rocprof_kernel_us(kernel_tag, traffic_source):
+    """Average duration of the dominant kernel in the committed rocprofv3 --kernel-trace --stats summary that belongs to the PMC
+    summary `traffic_source` (same tools/profile_all.sh run, same build hash): what the live HIP-event figure must agree with."""
+    if not traffic_source:
+        return None
+    path = os.path.join(ROOT, traffic_source.replace("_pmc.json", "_kernel_stats.csv"))
+    try:
+        for line in open(path):
+            if kernel_tag in line and "false, false, true>" in line:
+                cols = line.rsplit('",', 1)[1].split(",")  # Calls, TotalDurationNs, AverageNs, ...
+                return float(cols[2]) / 1e3
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def build_scene(rtc, local_rank, workload, mesh, levels):
     cfg, kind, _, _, _ = WORKLOADS[workload]
     dev = rtc.Device(f"gpu={local_rank},{cfg}")
@@ -348,6 +364,7 @@ def main():
                        "sharding": f"replicated accel, {world} independent ray shards, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_ms, "kernel": tag,
+                         "kernel_us_rocprofv3": rocprof_kernel_us(tag, traffic_src) if (m == 1_000_000 and levels == (6, 3) and args.rays_kind == "random" and not occluded) else None,
                          "aggregate_frac_in_flight": bytes_per_ray * m * K / elapsed / 1e9 / HBM_PEAK_GBS,
                          "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_node, "leaf_visits_per_ray": n_prim,
                          "inner_steps_per_ray": n_inner, "node_bytes": st["nodeBytes"], "leaf_bytes": st["primBytes"],
