@@ -123,8 +123,8 @@ struct Device : RefCounted
   HostPool hostPool;
   uint32_t tuneZeroCopyMax = 512;      // env RTAMD_ZEROCOPY_MAX: host batches up to this many rays are traced in place in pinned host memory (0 = never)
   uint32_t tuneHostThreads = 0;        // env RTAMD_HOST_THREADS (0: min(8, hardware threads / 2))
-  uint32_t tunePipeMinRays = 262144;   // env RTAMD_PIPE_MIN: host-pointer batches from this size on are pipelined in chunks
-  uint32_t tunePipeChunk = 131072;     // env RTAMD_PIPE_CHUNK: rays per chunk
+  uint32_t tunePipeMinRays = 16384;    // env RTAMD_PIPE_MIN: host-pointer batches from this size on are pipelined in chunks
+  uint32_t tunePipeChunk = 0;          // env RTAMD_PIPE_CHUNK: rays per chunk; 0 = by batch size (rt_trace.cpp, measured optima)
 
   // Call combiner for small host-pointer calls (rtcIntersect1 / rtcOccluded1 / short 1M streams from many threads):
   // whoever finds the device idle becomes the leader and traces everything that is pending - its own call and the

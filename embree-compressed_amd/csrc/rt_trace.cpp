@@ -326,7 +326,9 @@ static void trace_host_pipelined(Scene* s, char* rays, uint32_t M, size_t byteSt
 {
   Device* dev = s->device;
   const size_t G = M < 2u * dev->shards.size() ? 1 : dev->shards.size();
-  const uint32_t CH = dev->tunePipeChunk;
+  // chunk size by batch size (tools/pcie_probe.py and a sweep of 16 k .. 200 k rays on MI355X: 32 k rays in 16 k chunks 0.29 ms against 0.41 ms
+  // unpipelined, 64 k in 32 k chunks 0.41 / 0.70 ms, 128 k 0.69 / 1.20 ms, 200 k 0.99 / 1.79 ms, 1 M in 128 k chunks 2.84 / 9.4 ms)
+  const uint32_t CH = dev->tunePipeChunk ? dev->tunePipeChunk : (M < 49152u ? 16384u : (M < 300000u ? 32768u : (M < 600000u ? 65536u : 131072u)));
   const unsigned LAG = 2;
   if (dev->hostPool.threads.empty()) {
     const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
