@@ -997,6 +997,12 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
 
 template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t stream, uint32_t levels)
 {
+#ifdef TRACE_DEV_METRIC_ONLY
+  // Development builds (`make OUT=lib_wdev EXTRA=-DTRACE_DEV_METRIC_ONLY`, with the other objects copied from lib/: seconds instead of four
+  // minutes): only the metric's kernel is instantiated - cbvh.leaf, C = 3, quad form.  Everything else fails with hipErrorInvalidValue.
+  if constexpr (MODE == MODE_LEAF) { if (levels == 3 && !p.poolKernel && !p.cbvhLaneForm) return launch_leaf<CbvhLeaf<MODE, 3, true>, true>(p, stream); }
+  return hipErrorInvalidValue;
+#else
   if (p.poolKernel) switch (levels) {
     case 1: return launch_leaf_pool<CbvhLeaf<MODE, 1, false>, true>(p, stream);
     case 2: return launch_leaf_pool<CbvhLeaf<MODE, 2, false>, true>(p, stream);
@@ -1021,6 +1027,7 @@ template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t st
   case 5: return launch_leaf<CbvhLeaf<MODE, 5, true>, true>(p, stream);
   default: return hipErrorInvalidValue;
   }
+#endif
 }
 
 } // namespace dev
@@ -1028,9 +1035,11 @@ template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t st
 hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream)
 {
   switch (p.accel.kind) {
+#ifndef TRACE_DEV_METRIC_ONLY
   case ACCEL_GRIDSOA:
     if (p.poolKernel) return dev::launch_leaf_pool<dev::GridCellLeaf, true>(p, stream);
     return dev::launch_leaf<dev::GridCellLeaf, true>(p, stream);
+#endif
   case ACCEL_CBVH_BOX: return dev::launch_cbvh<dev::MODE_BOX>(p, stream, p.cbvhLevels);
   case ACCEL_CBVH_LEAF: return dev::launch_cbvh<dev::MODE_LEAF>(p, stream, p.cbvhLevels);
   case ACCEL_CBVH_GRID: return dev::launch_cbvh<dev::MODE_GRID>(p, stream, p.cbvhLevels);
