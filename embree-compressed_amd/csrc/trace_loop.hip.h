@@ -117,7 +117,18 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   // alone unchanged.
   // (All waves at 100 %: baseline; half of the waves at 85 %: +2 % / -6 % alone; four levels 70..100 %: +1 % / -10 %.)
   const uint32_t wIdx = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
-  const uint32_t stag = (wIdx & 3u) == 1u ? 85u : ((wIdx & 3u) == 3u ? 92u : 100u);
+  // (r2, second session, 4096 waves of the quad-form kernel: a THIRD class at 96 % - only a quarter of the waves drains the queues - takes a
+  // batch alone from 0.148 to 0.143 ms and four in flight from 11.5 to 11.6 Grays/s; levels swept with the metric-only dev build:
+  // 85/92/96 0.1426-0.1444 ms, 80/90/96 0.1431-0.1434, 88/94/98 0.1434-0.1456, 75/85/95 0.1429-0.1440 but -1.7 % in flight, 85/92/100 (before)
+  // 0.1471-0.1494, no staggering at all 0.1605)
+#ifndef TRACE_STAG_A
+#define TRACE_STAG_A 85u
+#define TRACE_STAG_B 92u
+#define TRACE_STAG_C 96u
+#endif
+  // (the third class only in the kernels that run four workgroups per CU - grid cells, cBVH quad form: one 256-ray chunk per wave; the triangle
+  // kernels, two workgroups per CU and two chunks per wave, lose with it: alone 0.102 -> 0.107 ms)
+  const uint32_t stag = (wIdx & 3u) == 1u ? TRACE_STAG_A : ((wIdx & 3u) == 3u ? TRACE_STAG_B : (((wIdx & 3u) == 2u && Leaf::OCTET_ONLY) ? TRACE_STAG_C : 100u));
   bool exhausted = P.accel.root == REF_EMPTY;
 
   WorkCounters wc;
