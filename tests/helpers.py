@@ -89,41 +89,79 @@ FORK_ORACLE_MODE = {"default": 2, "bvh4.compressed.box": 3, "bvh4.compressed.lea
 ORDERED_FORK = ("bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.full")
 
 
-def fork_parity_stats(got, want, rtol=1e-4):
-    """Disagreement statistics between two record sets of the same rays: hit/miss flips, ID flips among common hits, and
-    the number of common same-ID hits whose t / u / v differ by more than rtol (relative; u, v floored at 1e-3)."""
+def fork_parity_stats(got, want, rtol=1e-4, cell=None):
+    """Disagreement statistics between two record sets of the same rays, CLASSIFIED (round 3).
+
+    hitmiss_flips / id_flips as before.  Every common hit with equal IDs falls into exactly one class:
+      within     t, u and v within rtol (relative; u, v floored at 1e-3) - the north-star bar;
+      subcell    t within rtol, u or v beyond it, but max(|du|, |dv|) <= 0.25 cell: the same cell of the patch, the hit point moved
+                 by rounding (a box / height-field entry point at grazing incidence amplifies 1 ulp of t into ~1e-2 cells; relative
+                 to a u near 0 that is "beyond 1e-4" although it is ~1e-5 of the patch);
+      neighbour  max(|du|, |dv|) <= 1.125 cells (or t beyond rtol and uv within that bound): the ray took the neighbouring cell of
+                 the same patch (cells of the box / leaf modes are discontinuous approximations: in-slab test, `t < tt`, box entry
+                 points as hits - compressed.h:555-559, compressed_help.h:135-229; 1.125 = one cell + the slack of the conservative
+                 quantized cell boxes, measured maximum 1.045 in the box mode);
+      second     max(|du|, |dv|) <= 2.125 cells: leaf mode only, measured on 11 of 1.76 M hits (tools/parity_dryrun.py: 1920x1080
+                 camera rays 8, L6/C5 3; maximum 1.93 cells, t bit-identical): a height-field cell reads the entry / exit distances
+                 of the LAST decoded node (the fork's quirk, compressed.h:544-549) and measures the hit point against its own
+                 quantized box, so two cells that accept the same stale t report u or v up to two cells apart;
+      far        anything else - a FAILURE whatever its number.
+    `cell` = extent of one cell in the patch's uv (2^-L for a quad mesh); None: only the counts of the old report.
+    beyond = subcell + neighbour + second + far;  beyond_frac = beyond / hits of `want`."""
     gh, wh = got["geomID"] != INVALID, want["geomID"] != INVALID
     both = gh & wh
     idflip = both & ((got["primID"] != want["primID"]) | (got["geomID"] != want["geomID"]))
     same = both & ~idflip
     out = {"hits": int(wh.sum()), "hitmiss_flips": int((gh != wh).sum()), "id_flips": int(idflip.sum())}
-    worst = 0
+    rel = {}
     for f in ("tfar", "u", "v"):
         a, b = got[f][same].astype(np.float64), want[f][same].astype(np.float64)
-        rel = np.abs(a - b) / np.maximum(np.abs(b), 1e-3 if f != "tfar" else 1e-30)
-        out[f + "_beyond"] = int((rel > rtol).sum())
-        out[f + "_maxrel"] = float(rel.max()) if rel.size else 0.0
-        worst = max(worst, out[f + "_beyond"])
-    out["beyond_frac"] = worst / max(1, out["hits"])
+        rel[f] = np.abs(a - b) / np.maximum(np.abs(b), 1e-3 if f != "tfar" else 1e-30)
+        out[f + "_beyond"] = int((rel[f] > rtol).sum())
+        out[f + "_maxrel"] = float(rel[f].max()) if rel[f].size else 0.0
+    t_bad = rel["tfar"] > rtol
+    uv_bad = (rel["u"] > rtol) | (rel["v"] > rtol)
+    beyond = t_bad | uv_bad
+    out["beyond"] = int(beyond.sum())
+    out["beyond_frac"] = out["beyond"] / max(1, out["hits"])
+    if cell is not None:
+        du = np.abs(got["u"][same].astype(np.float64) - want["u"][same]) / cell
+        dv = np.abs(got["v"][same].astype(np.float64) - want["v"][same]) / cell
+        m = np.maximum(du, dv)
+        sub = beyond & ~t_bad & (m <= 0.25)
+        nb = beyond & ~sub & (m <= 1.125)
+        sec = beyond & ~sub & ~nb & (m <= 2.125)
+        far = beyond & ~sub & ~nb & ~sec
+        out.update(subcell=int(sub.sum()), neighbour=int(nb.sum()), second=int(sec.sum()), far=int(far.sum()),
+                   max_cells=float(m[beyond].max()) if beyond.any() else 0.0)
     return out
 
 
-def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None, flip_tol=2e-5, beyond_tol=0.006):
-    """Parity of the HIP kernels on one of the fork's cBVH modes, in two steps.
+# Measured floors of the classified comparison "product arithmetic vs reference arithmetic" (tools/parity_dryrun.py, round 3: the
+# kernels are byte-identical to the oracle in product arithmetic, so oracle(product) vs oracle(reference) on the CPU IS the GPU's
+# figure; profiles/r03_parity_report.txt has the GPU run).  beyond_frac bound = 2 x floor (VERDICT r2 #1b).
+FORK_BEYOND_FLOOR = {"bvh4.compressed.box": 0.0027, "bvh4.compressed.leaf": 0.0025, "bvh4.compressed.full": 0.0017}
+
+
+def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None, cell=None, beyond_floor=None, hitmiss_max=2, id_max=3):
+    """Parity of the HIP kernels on one of the fork's cBVH modes.
 
     trace_oracle() -> fresh oracle records for the same rays (called once per arithmetic mode).
-    1. Oracle in PRODUCT arithmetic (po.fork_arith(1): IEEE divisions, exact 1/16): the records must be byte-identical -
-       the kernels ARE the restated algorithm (visiting order, tie rules, quirks), checked on every field.  (Measured round 2
-       on 1 M rays, L6/C3: box 0 and grid 0 differing records, leaf 1 - same IDs and t, u one ulp and v 4e-6 apart; hence the
+    1. REGRESSION leg - oracle in PRODUCT arithmetic (po.fork_arith(1): IEEE divisions, exact 1/16): the records must be
+       byte-identical - the kernels ARE the restated algorithm (visiting order, tie rules, quirks), checked on every field.  Kernel and
+       oracle share authorship and arithmetic here: this guards against regressions of the device code, it is NOT the parity claim.
+       (Measured on 1 M rays, L6/C3: box 0 and grid 0 differing records, leaf 1 - same IDs and t, u one ulp and v 4e-6 apart; hence the
        allowance of one record per 250 000 rays, each within 1e-5.)
-    2. Oracle in REFERENCE arithmetic (default: rcp = rcpss + Newton step, rsqrt-based normalize, dpps dot - each pinned to
-       the reference's headers in tests/test_oracle.py): IDs and t/u/v are compared at the north-star tolerance (IDs exact,
-       1e-4 relative).  compressed.grid (true triangles) must meet it on every ray.  The box / leaf modes are discontinuous
-       approximations (in-slab tests, `t < tt`, box entry points as hits): a 1-ulp difference in a reciprocal moves a few rays
-       per thousand hits to the neighbouring cell of the same patch (same IDs, u/v one cell apart).  That sensitivity is the
-       fork's - its own results differ the same way between CPU vendors, whose rcpss tables differ - so for these two modes
-       the test bounds the fraction instead (measured round 2, L6/C3, 1 M rays: 0 hit/miss flips, <= 2 primID flips, 0.17 %
-       of the hits beyond 1e-4) and returns the numbers for the report."""
+    2. PARITY leg - oracle in REFERENCE arithmetic (default: rcp = rcpss + Newton step, rsqrt-based normalize, dpps dot - each pinned
+       to the reference's headers in tests/test_oracle.py), compared at the north-star tolerance (IDs exact, 1e-4 relative) and
+       CLASSIFIED (fork_parity_stats):
+         * compressed.grid (true triangles) must meet the tolerance on every ray;
+         * box / leaf / full: hit/miss flips <= hitmiss_max (2), ID flips <= id_max (3, absolute), NO record in class "far" - every
+           record beyond 1e-4 keeps its IDs and lies within one cell of the reference-arithmetic hit (leaf mode: at most
+           3 + 1e-5 x hits records within two cells, see fork_parity_stats) - and the fraction of records beyond 1e-4 at most
+           twice the measured floor of the mode (`beyond_floor`, default FORK_BEYOND_FLOOR).
+       `cell` = uv extent of one cell (2^-L on a quad mesh) and is required for these modes.  The traversal as a whole has no
+       reference-held vector: these rows stay "parity unpinned" (DESIGN.md section 5)."""
     with po.fork_arith(1):
         want_prod = trace_oracle()
     n = got.shape[0]
@@ -140,13 +178,22 @@ def check_fork_parity(po, got, trace_oracle, accel, what="", fork_geom=None, fli
     if len(bad):
         compare_hits(got[bad], want_prod[bad], rtol=1e-5, what=what + " (product arithmetic)")
     want_ref = trace_oracle()
-    st = fork_parity_stats(got, want_ref)
+    st = assert_fork_classes(got, want_ref, accel, what=what, cell=cell, beyond_floor=beyond_floor, hitmiss_max=hitmiss_max, id_max=id_max)
+    return st
+
+
+def assert_fork_classes(got, want_ref, accel, what="", cell=None, beyond_floor=None, hitmiss_max=2, id_max=3):
+    """The PARITY leg of check_fork_parity on two record sets (also used against the committed reference-arithmetic fixture)."""
+    st = fork_parity_stats(got, want_ref, cell=cell)
     print(f"[parity] {what}: {st}")
     if accel.endswith("grid"):
-        lim = 0 if flip_tol <= 2e-5 else max(2, int(st["hits"] * flip_tol))  # surface-origin rays: caller widens flip_tol
-        assert st["hitmiss_flips"] <= lim and st["id_flips"] <= lim and st["beyond_frac"] == 0.0, (what, st)
+        assert st["hitmiss_flips"] <= max(0, hitmiss_max - 2) and st["id_flips"] <= max(0, hitmiss_max - 2) and st["beyond"] == 0, (what, st)
     else:
-        assert st["hitmiss_flips"] <= max(2, int(st["hits"] * flip_tol)), (what, st)
-        assert st["id_flips"] <= max(3, st["hits"] // 10000), (what, st)
-        assert st["beyond_frac"] <= beyond_tol, (what, st)
+        assert cell is not None, "box / leaf / full modes: pass the uv extent of one cell"
+        floor = FORK_BEYOND_FLOOR[accel] if beyond_floor is None else beyond_floor
+        assert st["hitmiss_flips"] <= hitmiss_max, (what, st)
+        assert st["id_flips"] <= id_max, (what, st)
+        assert st["far"] == 0, (what, "records more than two cells away from the reference-arithmetic hit", st)
+        assert st["second"] <= (3 + 1e-5 * st["hits"] if accel.endswith("leaf") else 0), (what, "records more than one cell away", st)
+        assert st["beyond"] <= 2.0 * floor * st["hits"] + 3, (what, st)
     return st

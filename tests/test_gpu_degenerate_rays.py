@@ -120,9 +120,9 @@ def test_degenerate_rays_on_subdivision_accels(rtc, po, bomberman, accel):
     if accel == "default":
         nh = compare_hits(got, trace_oracle(), what=accel)
     else:
-        # (reference arithmetic: axis-parallel rays run along cell borders, and the sample of hits is small - 8 of 1 250 hits sit in
-        # the neighbouring cell of the same patch with the other reciprocal, 0.64 %)
-        check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} degenerate rays", beyond_tol=0.02)
+        # (reference arithmetic: axis-parallel rays run along cell borders, and the sample of hits is small - 10 of 1 250 hits are beyond 1e-4
+        # with the other reciprocal, 0.8 %, 8 of them in the same cell and 2 in the neighbouring one)
+        check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} degenerate rays", cell=2.0 ** -L, beyond_floor=0.008)
         nh = int((got["geomID"] != INVALID).sum())
     assert nh > (0.2 if accel == "default" else 0.02) * len(got)  # see the module docstring for the fork's modes
     assert sc.intersect1M_counted(src.copy())["stackSpills"] == 0

@@ -108,8 +108,10 @@ def test_secondary_and_shadow_rays_on_the_compressed_accels(rtc, po, bomberman, 
     got = src.copy()
     sc.intersect1M(got)
     # rays that start ON the approximated surface (tnear 0.001): self-intersection decisions sit at rounding level, a few hit/miss
-    # flips per 10 000 hits between the two arithmetics (measured: 1-3 of 15 000)
-    stt = check_fork_parity(po, got, trace_oracle, accel, what=f"secondary {accel}", flip_tol=5e-4)
+    # flips per 10 000 hits between the two arithmetics (measured, tools/parity_dryrun.py: 1-5 of 15 200; records beyond 1e-4: box
+    # 0.21 %, leaf 0.53 %, full 0.16 % - all in the same or the neighbouring cell)
+    stt = check_fork_parity(po, got, trace_oracle, accel, what=f"secondary {accel}", cell=2.0 ** -6, hitmiss_max=8,
+                            beyond_floor={"bvh4.compressed.leaf": 0.0055}.get(accel))
     assert 0 < stt["hits"] < src.shape[0]
     # shadow rays: the stub is order independent; the oracle's own full-precision tree over the blobs' bounds
     orc.free()

@@ -57,10 +57,18 @@ def test_bomberman_subdiv_parity(rtc, po, bomberman, accel, L, Cl, nrays):
     if accel == "default":
         nh = compare_hits(got, trace_oracle(), what=f"{accel} L{L} C{Cl}")
     else:
-        check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} L{L} C{Cl}")
+        check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} L{L} C{Cl}", cell=2.0 ** -L)
         nh = int((got["geomID"] != INVALID).sum())
-    if (L, Cl, nrays) == (6, 3, 1_000_000) and accel in ("default", "bvh4.compressed.grid"):
-        assert nh == 162_467  # reference output, SURVEY.md section 6 (eager GridSOA and compressed.grid)
+    if (L, Cl, nrays) == (6, 3, 1_000_000):
+        # reference outputs, SURVEY.md section 6 (measured there on the real library): eager GridSOA and compressed.grid exactly; the
+        # encoder-dependent modes within 3e-4 relative (ours 162 847 / 162 871 / 162 647: the survey's build solved the homography with its
+        # own Eigen stand-in)
+        ref_hits = {"default": 162_467, "bvh4.compressed.grid": 162_467, "bvh4.compressed.leaf": 162_823, "bvh4.compressed.box": 162_849,
+                    "bvh4.compressed.full": 162_646}[accel]
+        if accel in ("default", "bvh4.compressed.grid"):
+            assert nh == ref_hits
+        else:
+            assert abs(nh - ref_hits) <= 3e-4 * ref_hits, (accel, nh, ref_hits)
     cnt = sc.intersect1M_counted(po.make_random_rays(nrays, lo, hi, seed=0, double_eval=True))
     assert cnt["hits"] == nh and cnt["stackSpills"] == 0 and cnt["nodeVisits"] > 0
     # any-hit
@@ -156,7 +164,7 @@ def test_displaced_cube_with_ground_plane(rtc, po, accel):
     if accel == "default":
         nh = compare_hits(got, trace_oracle(), what=f"displaced cube {accel}")
     else:
-        check_fork_parity(po, got, trace_oracle, accel, what=f"displaced cube {accel}", fork_geom=g_sub)
+        check_fork_parity(po, got, trace_oracle, accel, what=f"displaced cube {accel}", fork_geom=g_sub, cell=2.0 ** -L)
         nh = int((got["geomID"] != INVALID).sum())
     hit_sub = int((got["geomID"] == g_sub).sum())
     assert hit_sub > 5000 and nh > hit_sub
@@ -190,7 +198,7 @@ def test_primary_rays_config4(rtc, po, bomberman, accel):
     if accel == "default":
         nh = compare_hits(got, trace_oracle(), what=f"primary {accel}")
     else:
-        check_fork_parity(po, got, trace_oracle, accel, what=f"primary {accel}")
+        check_fork_parity(po, got, trace_oracle, accel, what=f"primary {accel}", cell=2.0 ** -5)
         nh = int((got["geomID"] != INVALID).sum())
     assert nh > 0.7 * raw.shape[0]
     orc.free()
@@ -220,7 +228,7 @@ def test_primary_rays_config4_full_size(rtc, po, bomberman, accel):
 
     got = src.copy()
     sc.intersect1M(got)
-    stt = check_fork_parity(po, got, trace_oracle, accel, what=f"primary 1920x1080 {accel}")
+    stt = check_fork_parity(po, got, trace_oracle, accel, what=f"primary 1920x1080 {accel}", cell=2.0 ** -6)
     assert stt["hits"] > 0.7 * raw.shape[0]
     dev2 = rtc.Device(f"gpus=0:0,subdiv_accel={accel}")
     sc2 = rtc.Scene(dev2)
@@ -286,7 +294,7 @@ def test_config3_displacement_geometry_scene(rtc, po, accel):
     if accel == "default":
         compare_hits(got, trace_oracle(), what=f"config 3 {accel}")
     else:
-        check_fork_parity(po, got, trace_oracle, accel, what=f"config 3 {accel}", fork_geom=g_sub)
+        check_fork_parity(po, got, trace_oracle, accel, what=f"config 3 {accel}", fork_geom=g_sub, cell=2.0 ** -L)
     hit_cam = got[: cam.shape[0]]["geomID"]
     assert (hit_cam == g_sub).sum() > 0.1 * cam.shape[0] and (hit_cam == g_tri).sum() > 0.1 * cam.shape[0]
     orc_s.free()
@@ -342,7 +350,7 @@ def test_non_quad_faces_parity(rtc, po, accel):
     if accel == "default":
         nh = compare_hits(got, trace_oracle(), what=f"prism {accel}")
     else:
-        check_fork_parity(po, got, trace_oracle, accel, what=f"prism {accel}")
+        check_fork_parity(po, got, trace_oracle, accel, what=f"prism {accel}", cell=2.0 ** -3)  # triangles: three sub-patches at level L - 1
         nh = int((got["geomID"] != INVALID).sum())
     assert nh > 0.2 * n
     hit = got["geomID"] != INVALID
@@ -403,7 +411,7 @@ def test_compression_levels_parity(rtc, po, bomberman, accel, L, Cl):
 
     got = po.make_random_rays(200_000, verts.min(0), verts.max(0), seed=3, double_eval=True)
     sc.intersect1M(got)
-    check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} L{L} C{Cl}")
+    check_fork_parity(po, got, trace_oracle, accel, what=f"{accel} L{L} C{Cl}", cell=2.0 ** -L)
     assert int((got["geomID"] != INVALID).sum()) > 20_000
     orc.free()
     sc.release()

@@ -348,7 +348,8 @@ def test_leaf_quantiser_matches_the_forks_header(rtc, po):
 @pytest.mark.parametrize("accel,mode", [("default", 2), ("bvh4.compressed.box", 3), ("bvh4.compressed.leaf", 4), ("bvh4.compressed.grid", 5), ("bvh4.compressed.full", 6)])
 def test_subdiv_golden_fixture_is_reproduced(rtc, po, bomberman, accel, mode):
     """tests/golden/bomberman_subdiv_hits.npz (tests/golden/make_golden_subdiv.py): host pipeline (tessellator, encoders,
-    outer BVH) + oracle reproduce the committed hits; guards all of them against silent changes."""
+    outer BVH) + oracle reproduce the committed hits; guards all of them against silent changes.  REGRESSION vectors of this
+    implementation (product tessellator + product encoder + oracle in product arithmetic), not a parity claim."""
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "bomberman_subdiv_hits.npz"))
     verts, fs, fi = bomberman

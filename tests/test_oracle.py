@@ -151,7 +151,8 @@ def test_block_tie_rules(po):
 @pytest.mark.parametrize("mode", [0, 1])
 def test_golden_fixture(po, bomberman_tris, mode):
     """tests/golden/bomberman_tri_hits.npz (made by tests/golden/make_golden.py with this oracle after it had
-    been pinned above): guards the oracle itself against regressions and travels to the GPU box."""
+    been pinned above): REGRESSION vectors - they guard the oracle itself against drift and travel to the GPU box; the parity
+    anchors of the triangle path are the reference-held TriangleHitTest and the survey-recorded reference outputs above."""
     g = np.load(os.path.join(ROOT, "tests", "golden", "bomberman_tri_hits.npz"))
     verts, tris = bomberman_tris
     m = int(g["count"])
