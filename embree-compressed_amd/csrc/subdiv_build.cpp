@@ -5,6 +5,7 @@
 #include "subdiv_tess.h"
 
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <thread>
 
@@ -176,15 +177,20 @@ void build_subdiv_accel(Scene* s)
   else RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown subdiv accel " + name);
 
   std::vector<PatchGrid> grids;
+  const auto tBuild0 = std::chrono::steady_clock::now();
   for (unsigned gid = 0; gid < s->geometries.size(); gid++) {
     Geometry* g = s->geometries[gid];
     if (!g || !g->enabled || g->type != RTC_GEOMETRY_TYPE_SUBDIVISION) continue;
     if (g->timeSteps != 1) RT_THROW(RTC_ERROR_INVALID_OPERATION, "motion blur geometry is not supported by the device path");
-    tessellate_subdiv(g, gid, s->subdivisionLevel, grids);
+    tessellate_subdiv(g, gid, s->subdivisionLevel, grids, host_threads(s->device));
   }
   if (grids.empty()) return;
+  const auto tBuild1 = std::chrono::steady_clock::now();
   if (mode < 0) build_eager(s, grids, A);
   else build_cbvh(s, grids, A, (CbvhMode)mode);
+  if (s->device->verbose >= 2)
+    fprintf(stderr, "embree3-amd: subdivision commit: tessellation %.2f s, leaf encoding + BVH8 %.2f s (%zu patch grids)\n",
+            std::chrono::duration<double>(tBuild1 - tBuild0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild1).count(), grids.size());
   s->debugGrids.clear();
   if (s->device->keepGrids) {
     for (const PatchGrid& pg : grids) {

@@ -1,4 +1,5 @@
 #include "subdiv_tess.h"
+#include "subdiv_build.h"
 #include <map>
 #include <memory>
 #include <mutex>
@@ -691,16 +692,12 @@ static void patch_vertex_ids(const Level& lv, const std::vector<FaceMap>& faceMa
     }
 }
 
-void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out)
+// L refinement rounds of `cur` + limit stencils; emits the patch grids of the faces marked in `emit` (nullptr: all faces) in
+// face order.  `cur` is consumed.
+static void refine_and_emit(const Geometry* geom, unsigned geomID, unsigned L, Level& cur, const std::vector<FaceMap>& faceMap, RTCSubdivisionMode mode,
+                            bool first, const std::vector<uint8_t>* emit, std::vector<PatchGrid>& out)
 {
-  if (L > 10) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "subdivision level too high");
-  Level cur;
-  std::vector<FaceMap> faceMap;
-  bool first = true;
-  const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first);
-  if (cur.grid.empty()) return;
   const bool mixed = !first; // faces of other arity than 4 exist: the base level already is one Catmull-Clark step deep
-
   for (unsigned l = 0; l < L; l++) {
     Refiner r(cur, mode, first);
     r.accumulate();
@@ -719,17 +716,26 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
   std::unique_ptr<NormalEval> ne;
   if (displ) ne.reset(new NormalEval(cur, fin));
 
-  // limit positions are shared between faces: evaluate each vertex once
+  // limit positions are shared between faces: evaluate each vertex once (only the vertices of emitted faces when a subset is asked for)
   std::vector<D3> limit(cur.P.size());
-  for (uint32_t v = 0; v < cur.P.size(); v++) limit[v] = fin.limit_point(v, pinned);
+  if (!emit)
+    for (uint32_t v = 0; v < cur.P.size(); v++) limit[v] = fin.limit_point(v, pinned);
+  else {
+    std::vector<uint8_t> need(cur.P.size(), 0);
+    for (size_t f = 0; f < cur.grid.size(); f++)
+      if ((*emit)[f])
+        for (uint32_t v : cur.grid[f]) need[v] = 1;
+    for (uint32_t v = 0; v < cur.P.size(); v++)
+      if (need[v]) limit[v] = fin.limit_point(v, pinned);
+  }
 
   const size_t N = (size_t)w * w;
   const bool noBoundary = mode == RTC_SUBDIVISION_MODE_NO_BOUNDARY;
-  out.reserve(out.size() + cur.grid.size());
   std::vector<float> gu(N), gv(N), nx, ny, nz;
   std::vector<uint32_t> g;
   for (size_t f = 0; f < cur.grid.size(); f++) {
     const FaceMap& fm = faceMap[f];
+    if (emit && !(*emit)[f]) continue;
     if (mixed && fm.corners == 4 && fm.sub != 0) continue; // sub-quads 1..3 of a quad face are consumed with sub-quad 0
     patch_vertex_ids(cur, faceMap, f, g);
     if (noBoundary) { // RTC_SUBDIVISION_MODE_NO_BOUNDARY: patches touching the border are not rendered
@@ -778,6 +784,156 @@ void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::v
       geom->displacement(&args);
     }
   }
+}
+
+// Tessellation in CHUNKS of faces, on all host threads (round 3).  Catmull-Clark refinement is local: the level-l points of a face
+// depend on the face's one-ring only.  A chunk = a few neighbouring faces of the base level plus their one-ring (every face that
+// shares a vertex with a chunk face); that sub-mesh is refined L times on its own and only the chunk faces' grids are kept.  The cut
+// turns the outer border of the halo into an artificial mesh boundary; what is computed wrongly because of it moves inwards by one
+// ring of the CURRENT level per round: after round k the wrong points keep a distance of at least 2^-(k-1) base cells from the chunk
+// faces, i.e. two cells of the final level, while the limit (and normal) stencils of the chunk faces' border vertices reach one cell
+// out.  The grids are therefore the ones the whole-mesh refinement produces (same formulas on the same one-rings; only the order in
+// which a vertex's neighbours are summed can differ, in double precision, before the rounding to float).
+// Why: the whole-mesh refinement is one thread walking gigabytes (bomberman L6 2 s, L7 25 s, L8 125 s); chunks stay in cache and run
+// in parallel (rtcCommitScene is internally parallel in the reference too, scene.cpp:727-786).  The displacement callback is then
+// called concurrently from the builder threads, as the reference does (subdivpatch1base_eval.cpp:139-156 under parallel_for).
+static void tessellate_chunked(const Geometry* geom, unsigned geomID, unsigned L, const Level& base, const std::vector<FaceMap>& faceMap,
+                               RTCSubdivisionMode mode, bool first, unsigned threads, size_t chunkFaces, std::vector<PatchGrid>& out)
+{
+  const size_t nF = base.grid.size(), nV = base.P.size();
+  // faces of one control face stay together (a quad of a mixed mesh is re-assembled from its four sub-quads): group = run of equal primID
+  std::vector<uint32_t> groupOf(nF), groupStart;
+  for (size_t f = 0; f < nF; f++) {
+    if (f == 0 || faceMap[f].primID != faceMap[f - 1].primID) groupStart.push_back((uint32_t)f);
+    groupOf[f] = (uint32_t)groupStart.size() - 1;
+  }
+  groupStart.push_back((uint32_t)nF);
+  const size_t nG = groupStart.size() - 1;
+  // vertex -> faces (CSR)
+  std::vector<uint32_t> vStart(nV + 1, 0), vFaces;
+  for (const auto& g : base.grid)
+    for (uint32_t v : g) vStart[v + 1]++;
+  for (size_t v = 0; v < nV; v++) vStart[v + 1] += vStart[v];
+  vFaces.resize(vStart[nV]);
+  {
+    std::vector<uint32_t> fill(vStart.begin(), vStart.end() - 1);
+    for (size_t f = 0; f < nF; f++)
+      for (uint32_t v : base.grid[f]) vFaces[fill[v]++] = (uint32_t)f;
+  }
+  // chunks: breadth-first over vertex-adjacent groups, so that a chunk is a compact neighbourhood (small halo)
+  std::vector<std::vector<uint32_t>> chunks; // groups of each chunk
+  {
+    std::vector<uint8_t> taken(nG, 0);
+    for (size_t g0 = 0; g0 < nG; g0++) {
+      if (taken[g0]) continue;
+      std::vector<uint32_t> c{(uint32_t)g0};
+      taken[g0] = 1;
+      size_t faces = groupStart[g0 + 1] - groupStart[g0];
+      for (size_t head = 0; head < c.size() && faces < chunkFaces; head++)
+        for (uint32_t f = groupStart[c[head]]; f < groupStart[c[head] + 1] && faces < chunkFaces; f++)
+          for (uint32_t v : base.grid[f])
+            for (uint32_t k = vStart[v]; k < vStart[v + 1] && faces < chunkFaces; k++) {
+              const uint32_t g = groupOf[vFaces[k]];
+              if (taken[g]) continue;
+              taken[g] = 1;
+              c.push_back(g);
+              faces += groupStart[g + 1] - groupStart[g];
+            }
+      std::sort(c.begin(), c.end());
+      chunks.push_back(std::move(c));
+    }
+  }
+  std::vector<std::vector<PatchGrid>> results(chunks.size());
+  parallel_for_range(chunks.size(), threads, [&](size_t c0, size_t c1) {
+    std::vector<uint32_t> toLocal(nV, 0xFFFFFFFFu); // per worker call; chunks are few thousand vertices, the reset below is per chunk
+    for (size_t c = c0; c < c1; c++) {
+      // faces of the chunk, then every face that shares a vertex with one of them
+      std::vector<uint32_t> own, local;
+      for (uint32_t g : chunks[c])
+        for (uint32_t f = groupStart[g]; f < groupStart[g + 1]; f++) own.push_back(f);
+      local = own;
+      for (uint32_t f : own)
+        for (uint32_t v : base.grid[f])
+          for (uint32_t k = vStart[v]; k < vStart[v + 1]; k++) local.push_back(vFaces[k]);
+      std::sort(local.begin(), local.end());
+      local.erase(std::unique(local.begin(), local.end()), local.end());
+      // halo faces drag in the rest of their control face's group only when it matters: patch_vertex_ids looks at f .. f+3 of EMITTED faces
+      std::vector<uint32_t> verts;
+      for (uint32_t f : local)
+        for (uint32_t v : base.grid[f]) verts.push_back(v);
+      std::sort(verts.begin(), verts.end());
+      verts.erase(std::unique(verts.begin(), verts.end()), verts.end());
+      for (size_t i = 0; i < verts.size(); i++) toLocal[verts[i]] = (uint32_t)i;
+      Level lv;
+      lv.n = base.n;
+      lv.P.resize(verts.size());
+      lv.pinned.resize(verts.size());
+      lv.bpin.resize(verts.size());
+      if (!base.vcrease.empty()) lv.vcrease.assign(verts.size(), 0.f);
+      for (size_t i = 0; i < verts.size(); i++) {
+        const uint32_t v = verts[i];
+        lv.P[i] = base.P[v];
+        lv.pinned[i] = base.pinned[v];
+        lv.bpin[i] = base.bpin[v];
+        if (!base.vcrease.empty() && v < base.vcrease.size()) lv.vcrease[i] = base.vcrease[v];
+      }
+      std::vector<FaceMap> fmLocal;
+      std::vector<uint8_t> emit;
+      lv.grid.reserve(local.size());
+      size_t o = 0;
+      for (uint32_t f : local) {
+        std::vector<uint32_t> g = base.grid[f];
+        if (!base.crease.empty()) { // the 2x2 grid of a base face is (0,0) (1,0) (0,1) (1,1): its border edges
+          static const int E[4][2] = {{0, 1}, {1, 3}, {3, 2}, {2, 0}};
+          for (const auto& e : E) {
+            auto it = base.crease.find(edge_key(g[e[0]], g[e[1]]));
+            if (it != base.crease.end()) lv.crease[edge_key(toLocal[g[e[0]]], toLocal[g[e[1]]])] = it->second;
+          }
+        }
+        for (uint32_t& v : g) v = toLocal[v];
+        lv.grid.push_back(std::move(g));
+        fmLocal.push_back(faceMap[f]);
+        while (o < own.size() && own[o] < f) o++;
+        emit.push_back(o < own.size() && own[o] == f ? 1 : 0);
+      }
+      for (uint32_t v : verts) toLocal[v] = 0xFFFFFFFFu;
+      refine_and_emit(geom, geomID, L, lv, fmLocal, mode, first, &emit, results[c]);
+    }
+  });
+  // back into face order (chunks hold ascending groups, but interleave with each other)
+  struct Slot { uint32_t primID, sub; PatchGrid* pg; };
+  std::vector<Slot> slots;
+  for (auto& r : results)
+    for (PatchGrid& pg : r) slots.push_back(Slot{pg.primID, 0u, &pg});
+  // sub-patches of one control face were emitted in order inside their chunk; a stable sort by primID restores the global order
+  std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.primID < b.primID; });
+  out.reserve(out.size() + slots.size());
+  for (const Slot& sl : slots) out.push_back(std::move(*sl.pg));
+}
+
+void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out, unsigned threads)
+{
+  if (L > 10) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "subdivision level too high");
+  Level cur;
+  std::vector<FaceMap> faceMap;
+  bool first = true;
+  const RTCSubdivisionMode mode = build_base_level(geom, cur, faceMap, first);
+  if (cur.grid.empty()) return;
+  // chunked (parallel, cache-resident) from ~1 M final cells on; RTAMD_TESS_CHUNK=0 forces the whole-mesh refinement, =N sets the
+  // faces per chunk
+  static const char* env = getenv("RTAMD_TESS_CHUNK");
+  const size_t envChunk = env ? (size_t)atol(env) : (size_t)-1;
+  const double cells = (double)cur.grid.size() * (double)((size_t)1 << (2 * L));
+  const bool chunked = env ? envChunk != 0 : (cells >= 1.0e6 && cur.grid.size() >= 8);
+  if (!chunked) {
+    out.reserve(out.size() + cur.grid.size());
+    refine_and_emit(geom, geomID, L, cur, faceMap, mode, first, nullptr, out);
+    return;
+  }
+  // faces per chunk: enough work per chunk to amortise the halo (16 faces + ~24 halo faces), fewer when a level is large enough that the
+  // chunk's working set (~120 B per final vertex and face of the sub-mesh) would leave the caches
+  const size_t chunkFaces = env && envChunk ? envChunk : (L >= 8 ? 4 : (L >= 7 ? 8 : 16));
+  tessellate_chunked(geom, geomID, L, cur, faceMap, mode, first, std::max(1u, threads), chunkFaces, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -30,7 +30,8 @@ struct PatchGrid
 };
 
 // Tessellate every valid face of a subdivision geometry at level L.  Calls the displacement callback on the host.
-void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out);
+// `threads`: host threads for the chunked tessellation of large meshes (subdiv_tess.cpp tessellate_chunked).
+void tessellate_subdiv(const Geometry* geom, unsigned geomID, unsigned L, std::vector<PatchGrid>& out, unsigned threads = 1);
 
 // rtcInterpolate (row f4): triangle meshes (scene_triangle_mesh.cpp:214-270) and subdivision meshes (limit surface of any
 // vertex / vertex-attribute buffer with first and second derivatives; scene_subdiv_mesh.cpp:757-864).
