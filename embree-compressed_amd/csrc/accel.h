@@ -76,33 +76,58 @@ struct alignas(16) GridCell
 static_assert(sizeof(GridCell) == 160, "GridCell must be 160 bytes");
 
 // ---- fork: compressed per-sub-grid BVH ("cBVH") blob -------------------------------------------------------------
-// Header (CBVH_HEADER_BYTES) followed by elems 4-byte nodes, then (leaf mode) 4^C 2-byte height patches, then (grid
-// mode) (2^C+1)^2 float3 vertices; blob stride is a multiple of 16.  Mirrors CompressedBVH's members
-// (kernels/geometry/compressed.h:408-433) with offsets instead of host pointers, the 3x3 inverse of proj precomputed
-// (the reference inverts at run time, compressed.h:585,647), and the leaf's world bounds kept for the any-hit stub.
+// Mirrors CompressedBVH's members (kernels/geometry/compressed.h:408-433) with offsets instead of host pointers, the 3x3 inverse
+// of proj precomputed (the reference inverts at run time, compressed.h:585,647), and the leaf's world bounds kept for the any-hit
+// stub.  Round 3 layout, ordered by WHEN a visit needs a field, in 128-byte lines (the blob stride is a multiple of 128 and the
+// blob array is 128-byte aligned, so a line of a blob is a line of L2 / HBM):
+//   line 0  (CbvhHeader, bytes 0..127)   everything up to and including the frustum test and the projected ray: space, box, proj, a
+//           copy of the root node's word, rcp_edges, extent.  Most visits of incoherent rays end at the frustum test
+//           (compressed_help.h:109-133): they touch this ONE line (round 2: the same fields lay in two or three lines of a 448-byte
+//           record that started on a line boundary only every other blob).
+//   line 1  (CbvhMid, bytes 128..159, then the nodes from byte 160)   ids + uv window (commit only) and the 4-byte node words
+//           (compressed_node.h:261-295); C = 3: 32 + 84 bytes, one line.
+//   then    (leaf mode) 4^C 2-byte height patches (compressed_leaf.h:21-47), or (grid mode) (2^C+1)^2 float3 vertices, 16-byte
+//           aligned; C = 3 leaf mode: bytes 256..383, exactly line 2.
+//   tail    (CbvhTail, 64 bytes, 16-byte aligned)   iproj (flat-frame commits only) and the world bounds (any-hit stub only).
+// bomberman L6/C3 leaf mode: 512 B per blob (reference 396), 46 528 blobs = 23.8 MB.
 struct alignas(16) CbvhHeader
+{
+  float space[9];       // rows of the 3x3 world->local matrix: l = (dot(row0,p), dot(row1,p), dot(row2,p))
+  float box[10];        // frustum: z slab + four 2-D corner points (compressed.h:278-292)
+  float proj[9];        // row-major homography
+  uint32_t rootWord;    // copy of the first node word (coded modes), so that a visit rejected by the frustum test never leaves line 0
+  float rcp_edges;
+  float extent;
+  uint32_t levels;      // C
+};
+struct alignas(16) CbvhMid
 {
   uint32_t geomID, primID;
   float uv0x, uv0y, uv1x, uv1y; // uv[0], uv[1]
-  float rcp_edges;
-  float extent;
   uint32_t elems;       // (4^C-1)/3 inner nodes
   uint32_t grid_width;  // 2^C+1
-  uint32_t levels;      // C
-  uint32_t pad0;
-  float space[9];       // rows of the 3x3 world->local matrix: l = (dot(row0,p), dot(row1,p), dot(row2,p))
-  float proj[9];        // row-major homography
-  float iproj[9];       // row-major inverse homography
-  float box[10];        // frustum: z slab + four 2-D corner points (compressed.h:278-292)
-  float wlo[3], whi[3]; // world-space bounds handed to the outer BVH (bounds_o)
-  float pad1;
 };
-static const uint32_t CBVH_HEADER_BYTES = 224;
+struct alignas(16) CbvhTail
+{
+  float iproj[9];       // row-major inverse homography
+  float wlo[3], whi[3]; // world-space bounds handed to the outer BVH (bounds_o)
+  float pad;
+};
+static const uint32_t CBVH_HEADER_BYTES = 128, CBVH_MID_BYTES = 32, CBVH_TAIL_BYTES = 64, CBVH_NODES_OFFSET = CBVH_HEADER_BYTES + CBVH_MID_BYTES;
 // bvh4.compressed.full: a quadtree node holds its four child boxes as floats (the reference's NodeStorage<flavor::ref,32,32,32>,
 // compressed_node.h:371-389, 24 floats); here plane-major so that a quad reads one plane of its four children with one access:
 // lx[4], ux[4], ly[4], uy[4], lz[4], uz[4]
 static const uint32_t CBVH_FULL_NODE_BYTES = 96;
-static_assert(sizeof(CbvhHeader) == CBVH_HEADER_BYTES, "CbvhHeader must be 224 bytes");
+static_assert(sizeof(CbvhHeader) == CBVH_HEADER_BYTES && sizeof(CbvhMid) == CBVH_MID_BYTES && sizeof(CbvhTail) == CBVH_TAIL_BYTES, "cBVH blob sections");
+// section offsets of a blob of compression level C; mode: 0 box, 1 leaf, 2 grid, 3 full (CbvhMode / MODE_* of the kernels)
+constexpr uint32_t cbvh_elems(uint32_t C) { return ((1u << (2u * C)) - 1u) / 3u; }
+constexpr uint32_t cbvh_payload_offset(uint32_t C, uint32_t mode) { return (CBVH_NODES_OFFSET + cbvh_elems(C) * (mode == 3u ? CBVH_FULL_NODE_BYTES : 4u) + 15u) & ~15u; } // cells / grid
+constexpr uint32_t cbvh_tail_offset(uint32_t C, uint32_t mode)
+{
+  return (cbvh_payload_offset(C, mode) + (mode == 1u ? 2u << (2u * C) : (mode == 2u ? 12u * ((1u << C) + 1u) * ((1u << C) + 1u) : 0u)) + 15u) & ~15u;
+}
+constexpr uint32_t cbvh_stride(uint32_t C, uint32_t mode) { return (cbvh_tail_offset(C, mode) + CBVH_TAIL_BYTES + 127u) & ~127u; }
+static_assert(cbvh_payload_offset(3, 1) == 256 && cbvh_tail_offset(3, 1) == 384 && cbvh_stride(3, 1) == 512, "C = 3 leaf mode: header | mid + nodes | cells | tail, one line each");
 
 enum AccelKind : uint32_t
 {

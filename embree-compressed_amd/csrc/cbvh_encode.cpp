@@ -299,16 +299,7 @@ Box3f cbvh_decode_child(const CbvhNode& n, const Box3f& P, int loc)
   return r;
 }
 
-size_t cbvh_blob_bytes(unsigned C, CbvhMode mode)
-{
-  const size_t cells = (size_t)1 << (2 * C);
-  const size_t elems = (cells - 1) / 3;
-  const size_t w = ((size_t)1 << C) + 1;
-  size_t n = CBVH_HEADER_BYTES + elems * (mode == CBVH_FULL ? (size_t)CBVH_FULL_NODE_BYTES : 4);
-  if (mode == CBVH_LEAF) n += cells * 2;
-  if (mode == CBVH_GRID) n = ((n + 3) & ~(size_t)3) + w * w * 12;
-  return (n + 15) & ~(size_t)15;
-}
+size_t cbvh_blob_bytes(unsigned C, CbvhMode mode) { return cbvh_stride(C, (uint32_t)mode); } // section offsets: accel.h
 
 // CompressedBVH::CompressedBVH, compressed.h:49-337
 void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, unsigned y1, unsigned C, CbvhMode mode, uint8_t* blob,
@@ -320,8 +311,10 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
   const size_t elems = (((size_t)1 << (2 * C)) - 1) / 3;
   memset(blob, 0, cbvh_blob_bytes(C, mode));
   CbvhHeader* H = (CbvhHeader*)blob;
-  CbvhNode* nodes = (CbvhNode*)(blob + CBVH_HEADER_BYTES);
-  uint8_t* leaves = blob + CBVH_HEADER_BYTES + elems * 4;
+  CbvhMid* Hm = (CbvhMid*)(blob + CBVH_HEADER_BYTES);
+  CbvhTail* Ht = (CbvhTail*)(blob + cbvh_tail_offset(C, (uint32_t)mode));
+  CbvhNode* nodes = (CbvhNode*)(blob + CBVH_NODES_OFFSET);
+  uint8_t* leaves = blob + cbvh_payload_offset(C, (uint32_t)mode);
 
   std::vector<F3> v((size_t)width * height);
   for (unsigned y = 0; y < height; y++)
@@ -331,14 +324,14 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
     }
   const unsigned i00 = 0, i10 = width - 1, i01 = width * (height - 1), i11 = width * height - 1;
 
-  H->geomID = pg.geomID;
-  H->primID = pg.primID;
+  Hm->geomID = pg.geomID;
+  Hm->primID = pg.primID;
   const float fn = (float)pg.n;
-  H->uv0x = pg.u0 + (float)x0 / fn; H->uv0y = pg.v0 + (float)y0 / fn;           // grid_u/grid_v of the first vertex
-  H->uv1x = (pg.u0 + (float)x1 / fn) - H->uv0x; H->uv1y = (pg.v0 + (float)y1 / fn) - H->uv0y; // :85-86
+  Hm->uv0x = pg.u0 + (float)x0 / fn; Hm->uv0y = pg.v0 + (float)y0 / fn;           // grid_u/grid_v of the first vertex
+  Hm->uv1x = (pg.u0 + (float)x1 / fn) - Hm->uv0x; Hm->uv1y = (pg.v0 + (float)y1 / fn) - Hm->uv0y; // :85-86
   H->rcp_edges = 1.f / (float)(1u << C);                         // :88-89
-  H->elems = (uint32_t)elems;
-  H->grid_width = width;
+  Hm->elems = (uint32_t)elems;
+  Hm->grid_width = width;
   H->levels = C;
 
   // frame from the (un-displaced, in leaf mode) corner vertices, :91-126
@@ -424,7 +417,7 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
   for (unsigned l = 0; l < C; l++)
     for (size_t k = 0; k < hier[l].size(); k++) {
       if (mode == CBVH_FULL) { // Node<flavor::ref,...>::setAABB (compressed_node.h:669-685): the child boxes as they are
-        float* rec = (float*)(blob + CBVH_HEADER_BYTES) + (size_t)curr * (CBVH_FULL_NODE_BYTES / 4);
+        float* rec = (float*)(blob + CBVH_NODES_OFFSET) + (size_t)curr * (CBVH_FULL_NODE_BYTES / 4);
         for (int m = 0; m < 4; m++) {
           const Box3f& cbx = hier[l + 1][4 * k + m];
           rec[0 + m] = cbx.lo[0]; rec[4 + m] = cbx.hi[0];
@@ -486,7 +479,7 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
     }
   }
   if (use_grid) { // :329-335
-    float* g = (float*)(blob + ((CBVH_HEADER_BYTES + elems * 4 + 3) & ~(size_t)3));
+    float* g = (float*)(blob + cbvh_payload_offset(C, (uint32_t)mode));
     for (size_t i = 0; i < v.size(); i++) { g[3 * i] = v[i].x; g[3 * i + 1] = v[i].y; g[3 * i + 2] = v[i].z; }
   }
 
@@ -495,9 +488,10 @@ void cbvh_encode(const PatchGrid& pg, unsigned x0, unsigned x1, unsigned y0, uns
   H->space[3] = space.vx.y; H->space[4] = space.vy.y; H->space[5] = space.vz.y;
   H->space[6] = space.vx.z; H->space[7] = space.vy.z; H->space[8] = space.vz.z;
   memcpy(H->proj, proj.m, 36);
-  memcpy(H->iproj, iproj.m, 36);
-  H->wlo[0] = boundsOut.lo.x; H->wlo[1] = boundsOut.lo.y; H->wlo[2] = boundsOut.lo.z;
-  H->whi[0] = boundsOut.hi.x; H->whi[1] = boundsOut.hi.y; H->whi[2] = boundsOut.hi.z;
+  memcpy(Ht->iproj, iproj.m, 36);
+  Ht->wlo[0] = boundsOut.lo.x; Ht->wlo[1] = boundsOut.lo.y; Ht->wlo[2] = boundsOut.lo.z;
+  Ht->whi[0] = boundsOut.hi.x; Ht->whi[1] = boundsOut.hi.y; Ht->whi[2] = boundsOut.hi.z;
+  if (mode != CBVH_FULL) memcpy(&H->rootWord, nodes, 4); // line 0 carries the root's word: a visit rejected by the frustum test reads nothing else
 }
 
 } // namespace rtamd

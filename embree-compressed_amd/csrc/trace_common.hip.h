@@ -316,32 +316,75 @@ __device__ __forceinline__ bool moeller(const RayState& r, const float4 A, const
 // ---------------------------------------------------------------------------------------------------
 // ray record I/O.  RTCRayHit: [org.xyz tnear][dir.xyz time][tfar mask id flags][Ng.xyz u][v primID geomID instID]
 // ---------------------------------------------------------------------------------------------------
+// Ray records are read once and hit records written once per batch: streamed with the non-temporal hint (global_load / store ... nt),
+// so that 80 MB of rays per million do not evict the accel (BVH8 nodes + blobs) from the 4 MiB L2 of an XCD.  TRACE_RAY_NT=0: plain accesses.
+#ifndef TRACE_RAY_NT
+#define TRACE_RAY_NT 1
+#endif
+#ifndef TRACE_HIT_NT
+#define TRACE_HIT_NT 0 // (measured r3: non-temporal 16-byte hit stores cost the metric kernel 12-20 B of scratch per lane at its 128-VGPR limit; hits are 16 % of the rays)
+#endif
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream4(const float4* p)
+{
+#if TRACE_RAY_NT
+  const f32x4_nt v = __builtin_nontemporal_load((const f32x4_nt*)p);
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ float ld_stream(const float* p)
+{
+#if TRACE_RAY_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_stream4(float4* p, float4 v)
+{
+#if TRACE_HIT_NT
+  f32x4_nt w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, (f32x4_nt*)p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(float* p, float v)
+{
+#if TRACE_HIT_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 template <bool VEC> __device__ __forceinline__ void load_ray(const char* p, RayState& r)
 {
   if (VEC) {
-    const float4 a = ((const float4*)p)[0];
-    const float4 b = ((const float4*)p)[1];
-    const float c = ((const float*)p)[8];
+    const float4 a = ld_stream4((const float4*)p);
+    const float4 b = ld_stream4((const float4*)p + 1);
+    const float c = ld_stream((const float*)p + 8);
     r.ox = a.x; r.oy = a.y; r.oz = a.z; r.tnear = a.w;
     r.dx = b.x; r.dy = b.y; r.dz = b.z; r.tfar = c;
   } else {
     const float* f = (const float*)p;
-    r.ox = f[0]; r.oy = f[1]; r.oz = f[2]; r.tnear = f[3];
-    r.dx = f[4]; r.dy = f[5]; r.dz = f[6]; r.tfar = f[8];
+    r.ox = ld_stream(f); r.oy = ld_stream(f + 1); r.oz = ld_stream(f + 2); r.tnear = ld_stream(f + 3);
+    r.dx = ld_stream(f + 4); r.dy = ld_stream(f + 5); r.dz = ld_stream(f + 6); r.tfar = ld_stream(f + 8);
   }
 }
 
 template <bool VEC> __device__ __forceinline__ void store_hit(char* p, const RayState& r, uint32_t instID)
 {
-  ((float*)p)[8] = r.tfar;
+  st_stream((float*)p + 8, r.tfar);
   if (VEC) {
-    ((float4*)p)[3] = make_float4(r.ngx, r.ngy, r.ngz, r.u);
-    ((float4*)p)[4] = make_float4(r.v, __uint_as_float(r.primID), __uint_as_float(r.geomID), __uint_as_float(instID));
+    st_stream4((float4*)p + 3, make_float4(r.ngx, r.ngy, r.ngz, r.u));
+    st_stream4((float4*)p + 4, make_float4(r.v, __uint_as_float(r.primID), __uint_as_float(r.geomID), __uint_as_float(instID)));
   } else {
     float* f = (float*)p;
-    uint32_t* w = (uint32_t*)p;
-    f[12] = r.ngx; f[13] = r.ngy; f[14] = r.ngz; f[15] = r.u; f[16] = r.v;
-    w[17] = r.primID; w[18] = r.geomID; w[19] = instID;
+    st_stream(f + 12, r.ngx); st_stream(f + 13, r.ngy); st_stream(f + 14, r.ngz); st_stream(f + 15, r.u); st_stream(f + 16, r.v);
+    st_stream(f + 17, __uint_as_float(r.primID)); st_stream(f + 18, __uint_as_float(r.geomID)); st_stream(f + 19, __uint_as_float(instID));
   }
 }
 

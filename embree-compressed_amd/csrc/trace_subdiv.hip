@@ -281,11 +281,17 @@ struct CbvhCtx
 template <int LEVELS> struct CbvhGeom
 {
   static constexpr uint32_t ELEMS = ((1u << (2 * LEVELS)) - 1u) / 3u; // inner nodes of the complete quadtree
-  static __device__ __forceinline__ const uint32_t* nodes(const CbvhHeader* H) { return (const uint32_t*)((const uint8_t*)H + CBVH_HEADER_BYTES); }
-  static __device__ __forceinline__ const uint8_t* leaves(const CbvhHeader* H) { return (const uint8_t*)H + CBVH_HEADER_BYTES + 4u * ELEMS; }
-  static __device__ __forceinline__ const float* grid(const CbvhHeader* H) { return (const float*)((const uint8_t*)H + CBVH_HEADER_BYTES + 4u * ELEMS); }
-  static __device__ __forceinline__ const float* fullNode(const CbvhHeader* H, uint32_t curr) { return (const float*)((const uint8_t*)H + CBVH_HEADER_BYTES) + 24u * curr; }
+  // section offsets of the blob: accel.h (line 0 = CbvhHeader, then CbvhMid + nodes, then cells / grid, then CbvhTail)
+  static __device__ __forceinline__ const uint32_t* nodes(const CbvhHeader* H) { return (const uint32_t*)((const uint8_t*)H + CBVH_NODES_OFFSET); }
+  static __device__ __forceinline__ const uint8_t* leaves(const CbvhHeader* H) { return (const uint8_t*)H + cbvh_payload_offset(LEVELS, MODE_LEAF); }
+  static __device__ __forceinline__ const float* grid(const CbvhHeader* H) { return (const float*)((const uint8_t*)H + cbvh_payload_offset(LEVELS, MODE_GRID)); }
+  static __device__ __forceinline__ const float* fullNode(const CbvhHeader* H, uint32_t curr) { return (const float*)((const uint8_t*)H + CBVH_NODES_OFFSET) + 24u * curr; }
 };
+__device__ __forceinline__ const CbvhMid* cbvh_mid(const CbvhHeader* H) { return (const CbvhMid*)((const uint8_t*)H + CBVH_HEADER_BYTES); }
+template <int MODE, int LEVELS> __device__ __forceinline__ const CbvhTail* cbvh_tail(const CbvhHeader* H)
+{
+  return (const CbvhTail*)((const uint8_t*)H + cbvh_tail_offset(LEVELS, MODE));
+}
 typedef float f32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
 
 __device__ __forceinline__ void project3(const float* m, float x, float y, float z, float& ox, float& oy, float& oz)
@@ -307,21 +313,22 @@ __device__ __forceinline__ float intersect_line(float p2x, float p2y, float p3x,
 }
 
 // commit a hit found inside the blob (compressed.h:570-591 / :631-653)
-template <bool ROW = false> __device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float t)
+template <int MODE, int LEVELS, bool ROW = false> __device__ __forceinline__ void cbvh_commit(CbvhCtx& c, float u, float v, float t)
 {
   RayState& r = *c.r;
   const CbvhHeader* H = c.H;
-  r.u = H->uv0x + u * H->uv1x;
-  r.v = H->uv0y + v * H->uv1y;
+  const CbvhMid* M = cbvh_mid(H);
+  r.u = M->uv0x + u * M->uv1x;
+  r.v = M->uv0y + v * M->uv1y;
   r.ngx = 1.f; r.ngy = 0.f; r.ngz = 0.f; // dummy normal
-  r.geomID = H->geomID;
-  r.primID = H->primID;
+  r.geomID = M->geomID;
+  r.primID = M->primID;
   r.hit = 1u;
   c.tfar = t;
   if (c.special) {
     // flat frame: un-project the local hit point and measure the distance in the rotated world frame (:583-587)
     float px, py, pz;
-    project3(H->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
+    project3(cbvh_tail<MODE, LEVELS>(H)->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
     const float* S = H->space; // lOrg again (same fma chain as at blob entry)
     const float rox = ROW ? c.row[0] : r.ox, roy = ROW ? c.row[1] : r.oy, roz = ROW ? c.row[2] : r.oz;
     const float lox = madd(rox, S[0], madd(roy, S[1], roz * S[2]));
@@ -431,10 +438,10 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz,
     const float z3 = off + rcpF * (float)(z34 >> 4), z4 = off + rcpF * (float)(z34 & 0xf);
     float u, v, t = c.tfar;
     if (COUNT) wc.inner++;
-    if (intersect_patch(idx, c.H->rcp_edges, dz, tN, tF, z1, z2, z3, z4, blx, bly, bhx, bhy, c, u, v, t)) cbvh_commit(c, u, v, t);
+    if (intersect_patch(idx, c.H->rcp_edges, dz, tN, tF, z1, z2, z3, z4, blx, bly, bhx, bhy, c, u, v, t)) cbvh_commit<MODE, LEVELS>(c, u, v, t);
   } else if (MODE == MODE_GRID) { // compressed.h:597-611, compressed_help.h:278-308
     const uint32_t x = compact1by1(idx), y = compact1by1(idx >> 1);
-    const uint32_t w = c.H->grid_width;
+    const uint32_t w = (1u << LEVELS) + 1u; // grid_width
     const float* g0 = CbvhGeom<LEVELS>::grid(c.H) + 3 * (y * w + x);
     const float* g1 = g0 + 3;
     const float* g2 = g0 + 3 * w;
@@ -448,10 +455,11 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz,
       const float uu = hit2 ? ((float)x + (1.f - r.u)) * c.H->rcp_edges : ((float)x + r.u) * c.H->rcp_edges;
       const float vv = hit2 ? ((float)y + (1.f - r.v)) * c.H->rcp_edges : ((float)y + r.v) * c.H->rcp_edges;
       r.ngx = 1.f; r.ngy = 0.f; r.ngz = 0.f;
-      r.u = c.H->uv0x + uu * c.H->uv1x;
-      r.v = c.H->uv0y + vv * c.H->uv1y;
-      r.geomID = c.H->geomID;
-      r.primID = c.H->primID;
+      const CbvhMid* M = cbvh_mid(c.H);
+      r.u = M->uv0x + uu * M->uv1x;
+      r.v = M->uv0y + vv * M->uv1y;
+      r.geomID = M->geomID;
+      r.primID = M->primID;
       r.hit = 1u;
       c.tfar = (r.tfar - c.near) * c.zFactor;
     }
@@ -461,7 +469,7 @@ __device__ __forceinline__ void cbvh_cell(CbvhCtx& c, uint32_t idx, uint32_t zz,
       const float u = (((c.ox + c.dx * is) - blx) / (bhx - blx) + (float)compact1by1(idx)) * c.H->rcp_edges;
       const float v = (((c.oy + c.dy * is) - bly) / (bhy - bly) + (float)compact1by1(idx >> 1)) * c.H->rcp_edges;
       if (COUNT) wc.inner++;
-      cbvh_commit(c, u, v, is);
+      cbvh_commit<MODE, LEVELS>(c, u, v, is);
     }
   }
 }
@@ -606,18 +614,20 @@ __device__ __forceinline__ uint32_t quad_ballot(bool p, uint32_t lid) { return (
 // distance of the hit so far, 4 `near`, 5 zFactor, 6 `special`, 7 / 8 u / v of the hit so far, 9 hit flag.  The commit-only part of
 // the context and the hit itself live there instead of in seven registers; all four lanes write the same values.
 enum : int { QR_TFAR = 3, QR_NEAR = 4, QR_ZFACTOR = 5, QR_SPECIAL = 6, QR_U = 7, QR_V = 8, QR_HIT = 9 };
+template <int MODE, int LEVELS>
 __device__ __forceinline__ void quad_commit(CbvhCtx& c, float u, float v, float t) // cbvh_commit for the leaf / box modes of the quad form
 {
   const CbvhHeader* H = c.H;
+  const CbvhMid* M = cbvh_mid(H);
   float* x = (float*)c.row;
-  x[QR_U] = H->uv0x + u * H->uv1x;
-  x[QR_V] = H->uv0y + v * H->uv1y;
+  x[QR_U] = M->uv0x + u * M->uv1x;
+  x[QR_V] = M->uv0y + v * M->uv1y;
   x[QR_HIT] = __uint_as_float(1u);
   c.tfar = t;
   if (__float_as_uint(x[QR_SPECIAL]) != 0u) {
     // flat frame: un-project the local hit point and measure the distance in the rotated world frame (:583-587)
     float px, py, pz;
-    project3(H->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
+    project3(cbvh_tail<MODE, LEVELS>(H)->iproj, c.ox + c.dx * t, c.oy + c.dy * t, c.oz + c.dz * t, px, py, pz);
     const float* S = H->space; // lOrg again (same fma chain as at blob entry)
     const float rox = x[0], roy = x[1], roz = x[2];
     const float lox = madd(rox, S[0], madd(roy, S[1], roz * S[2]));
@@ -713,7 +723,7 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
       const uint32_t acc = quad_ballot(tested && (kind == 1u || (kind == 2u && ct < c.tfar)), lid);
       if (acc != 0u) {
         const uint32_t src = (uint32_t)__ffs(acc) - 1u;
-        quad_commit(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(ct, src, lid));
+        quad_commit<MODE, LEVELS>(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(ct, src, lid));
       }
     }
   } else if constexpr (MODE == MODE_BOX || MODE == MODE_FULL) { // voxel, compressed.h:614-654: the box entry point is the hit
@@ -729,7 +739,7 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
       const uint32_t acc = quad_ballot(take, lid);
       if (acc != 0u) {
         const uint32_t src = (uint32_t)__ffs(acc) - 1u;
-        quad_commit(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(tN, src, lid));
+        quad_commit<MODE, LEVELS>(c, quad_getf(cu, src, lid), quad_getf(cv, src, lid), quad_getf(tN, src, lid));
       }
     }
   } else { // MODE_GRID (compressed.h:597-611): true triangles on the world ray, one cell after the other on all four lanes
@@ -756,9 +766,7 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
   static constexpr bool HIT_IN_MEMORY = QUAD; // quad form: a hit is written to the ray record when it is found; only tfar stays in registers
   static __device__ __forceinline__ bool octet_ok(const LaunchParams&) { return true; }
   // bytes of a blob of this mode and level (cbvh_blob_bytes, cbvh_encode.cpp)
-  static constexpr uint32_t BLOB_RAW = CBVH_HEADER_BYTES + CbvhGeom<LEVELS>::ELEMS * (MODE == MODE_FULL ? CBVH_FULL_NODE_BYTES : 4u) +
-                                       (MODE == MODE_LEAF ? 2u << (2 * LEVELS) : 0u);
-  static constexpr uint32_t BLOB_BYTES = ((MODE == MODE_GRID ? ((BLOB_RAW + 3u) & ~3u) + 12u * ((1u << LEVELS) + 1u) * ((1u << LEVELS) + 1u) : BLOB_RAW) + 15u) & ~15u;
+  static constexpr uint32_t BLOB_BYTES = cbvh_stride(LEVELS, MODE);
 
   // Quad form of intersect() below for the ray in exchange row `x` (words 0..7 = org, tnear, dir, tfar; word 8 = leaf ref); lane
   // q of the quad `lid >> 2`.  On a hit lane 0 of the quad writes tfar, u, v, geomID, primID into words 0, 4..7 and sets word 9.
@@ -773,7 +781,6 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     r.hit = 0u;
     const uint32_t idx = __float_as_uint(x[8]) & 0x7FFFFFFFu;
     const CbvhHeader* H = (const CbvhHeader*)(P.accel.blobs + (size_t)idx * P.accel.blobStride);
-    if (COUNT && q == 0u) wc.prims++;
 #if TRACE_CBVH_PREFETCH
     // The header fills the first two 128-byte lines of a blob; the deeper nodes and the cells lie in the next ones, and the walk
     // would meet each of them as a separate dependent miss.  Their first touch is issued here, together with the header's.
@@ -781,12 +788,13 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     if (!OCCLUDED) pf = ((const uint32_t*)H)[min(64u + 32u * (q & 1u), BLOB_BYTES / 4u - 1u)];
 #endif
     if (OCCLUDED) { // the fork's occluded() stub (compressed.h:754-756): see intersect() below
+      const CbvhTail* T = cbvh_tail<MODE, LEVELS>(H);
       const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx, zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy, zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
       const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
       const float rnx = 1.0f / zx, rny = 1.0f / zy, rnz = 1.0f / zz;
-      const float nx = ((rnx >= 0.f ? H->wlo[0] : H->whi[0]) - r.ox) * rnx, fx = ((rnx >= 0.f ? H->whi[0] : H->wlo[0]) - r.ox) * (rnx * ulp3);
-      const float ny = ((rny >= 0.f ? H->wlo[1] : H->whi[1]) - r.oy) * rny, fy = ((rny >= 0.f ? H->whi[1] : H->wlo[1]) - r.oy) * (rny * ulp3);
-      const float nz = ((rnz >= 0.f ? H->wlo[2] : H->whi[2]) - r.oz) * rnz, fz = ((rnz >= 0.f ? H->whi[2] : H->wlo[2]) - r.oz) * (rnz * ulp3);
+      const float nx = ((rnx >= 0.f ? T->wlo[0] : T->whi[0]) - r.ox) * rnx, fx = ((rnx >= 0.f ? T->whi[0] : T->wlo[0]) - r.ox) * (rnx * ulp3);
+      const float ny = ((rny >= 0.f ? T->wlo[1] : T->whi[1]) - r.oy) * rny, fy = ((rny >= 0.f ? T->whi[1] : T->wlo[1]) - r.oy) * (rny * ulp3);
+      const float nz = ((rnz >= 0.f ? T->wlo[2] : T->whi[2]) - r.oz) * rnz, fz = ((rnz >= 0.f ? T->whi[2] : T->wlo[2]) - r.oz) * (rnz * ulp3);
       const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, fmaxf(r.tnear, 0.f)));
       const float tf = fminf(fminf(fx, fy), fminf(fz, fmaxf(r.tfar, 0.f)));
       if (q == 0u && tn <= tf) x[9] = __uint_as_float(1u);
@@ -796,7 +804,7 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     c.H = H;
     c.r = &r;
     c.row = x;
-    const uint32_t rootWord = CbvhGeom<LEVELS>::nodes(H)[0];
+    const uint32_t rootWord = H->rootWord; // line 0 (accel.h): nothing outside it is read before the frustum test
     // rotate the ray into the local frame (:458-459), on all four lanes
     const float* S = H->space;
     const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
@@ -822,6 +830,7 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
       far = fminf(fminf(fmaxf(t1z, t2z), far1), far);
       if (!(near <= far && near1 == near1 && far1 == far1)) return;
     }
+    if (COUNT && q == 0u) wc.prims++; // counters of a cBVH accel: leaves = blob visits, prims = visits that pass the frustum test (walks), inner = quadtree nodes entered + cells tested
 #if TRACE_CBVH_PREFETCH
     asm volatile("" ::"v"(pf)); // (loads return in order: this costs no wait beyond the header's)
 #endif
@@ -878,11 +887,11 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
       if (q == 0u && __float_as_uint(x[QR_HIT]) != 0u) { // results into the words the kernel skeleton reads (ids from the header)
         const float t = x[QR_TFAR], u = x[QR_U], v = x[QR_V];
         x[0] = t; x[4] = u; x[5] = v;
-        x[6] = __uint_as_float(H->geomID); x[7] = __uint_as_float(H->primID);
+        x[6] = __uint_as_float(cbvh_mid(H)->geomID); x[7] = __uint_as_float(cbvh_mid(H)->primID);
       }
     } else if (q == 0u && r.hit) {
       x[0] = r.tfar; x[4] = r.u; x[5] = r.v;
-      x[6] = __uint_as_float(H->geomID); x[7] = __uint_as_float(H->primID);
+      x[6] = __uint_as_float(cbvh_mid(H)->geomID); x[7] = __uint_as_float(cbvh_mid(H)->primID);
       x[9] = __uint_as_float(1u);
     }
   }
@@ -904,16 +913,16 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     const uint32_t idx = ref & 0x7FFFFFFFu;
     const uint8_t* blob = P.accel.blobs + (size_t)idx * P.accel.blobStride;
     const CbvhHeader* H = (const CbvhHeader*)blob;
-    if (COUNT) wc.prims++;
     if (OCCLUDED) {
       // the fork's occluded() is a stub returning true for every leaf the outer traversal reaches
       // (compressed.h:754-756): the leaf is reached iff the robust slab test of its bounds passes
+      const CbvhTail* T = cbvh_tail<MODE, LEVELS>(H);
       const float zx = fabsf(r.dx) < 1e-18f ? 1e-18f : r.dx, zy = fabsf(r.dy) < 1e-18f ? 1e-18f : r.dy, zz = fabsf(r.dz) < 1e-18f ? 1e-18f : r.dz;
       const float ulp3 = 1.0f + 3.0f * 1.1920929e-7f;
       const float rnx = 1.0f / zx, rny = 1.0f / zy, rnz = 1.0f / zz;
-      const float nx = ((rnx >= 0.f ? H->wlo[0] : H->whi[0]) - r.ox) * rnx, fx = ((rnx >= 0.f ? H->whi[0] : H->wlo[0]) - r.ox) * (rnx * ulp3);
-      const float ny = ((rny >= 0.f ? H->wlo[1] : H->whi[1]) - r.oy) * rny, fy = ((rny >= 0.f ? H->whi[1] : H->wlo[1]) - r.oy) * (rny * ulp3);
-      const float nz = ((rnz >= 0.f ? H->wlo[2] : H->whi[2]) - r.oz) * rnz, fz = ((rnz >= 0.f ? H->whi[2] : H->wlo[2]) - r.oz) * (rnz * ulp3);
+      const float nx = ((rnx >= 0.f ? T->wlo[0] : T->whi[0]) - r.ox) * rnx, fx = ((rnx >= 0.f ? T->whi[0] : T->wlo[0]) - r.ox) * (rnx * ulp3);
+      const float ny = ((rny >= 0.f ? T->wlo[1] : T->whi[1]) - r.oy) * rny, fy = ((rny >= 0.f ? T->whi[1] : T->wlo[1]) - r.oy) * (rny * ulp3);
+      const float nz = ((rnz >= 0.f ? T->wlo[2] : T->whi[2]) - r.oz) * rnz, fz = ((rnz >= 0.f ? T->whi[2] : T->wlo[2]) - r.oz) * (rnz * ulp3);
       const float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, fmaxf(r.tnear, 0.f)));
       const float tf = fminf(fminf(fx, fy), fminf(fz, fmaxf(r.tfar, 0.f)));
       return tn <= tf;
@@ -924,7 +933,7 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     c.dbgRay = rayIdxDbg;
 #endif
     c.H = H;
-    const uint32_t rootWord = CbvhGeom<LEVELS>::nodes(H)[0]; // requested together with the header: no extra round trip after the frustum test
+    const uint32_t rootWord = H->rootWord; // line 0 (accel.h), requested together with the rest of the header: no extra round trip after the frustum test
     c.r = &r;
     // rotate the ray into the local frame (:458-459; xfmPoint/xfmVector are fma chains, linearspace3.h:168-169)
     const float* S = H->space;
@@ -952,9 +961,10 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
       far = fminf(fminf(fmaxf(t1z, t2z), far1), far);
       if (!(near <= far && near1 == near1 && far1 == far1)) return false;
     }
+    if (COUNT) wc.prims++; // visits that pass the frustum test (see octet_pass)
     c.near = near;
 #ifdef RTAMD_TRACE_RAY
-    if (rayIdxDbg == RTAMD_TRACE_RAY) printf("  GPU blob prim %u: lOrg %a %a %a lDir %a %a %a near %a far %a ray.tfar %a\n", H->primID, lox, loy, loz, ldx, ldy, ldz, near, far, r.tfar);
+    if (rayIdxDbg == RTAMD_TRACE_RAY) printf("  GPU blob prim %u: lOrg %a %a %a lDir %a %a %a near %a far %a ray.tfar %a\n", cbvh_mid(H)->primID, lox, loy, loz, ldx, ldy, ldz, near, far, r.tfar);
 #endif
 
     // projected ray between entry and exit point (:470-508)

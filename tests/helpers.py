@@ -83,6 +83,33 @@ def random_rays_np(m, lo, hi, seed):
     return p1, d
 
 
+# cBVH blob sections of the product (embree-compressed_amd/csrc/accel.h, round-3 layout): 128-byte line 0, ids / uv, node words from
+# byte 160, cells / grid 16-byte aligned, 64-byte tail; stride = multiple of 128
+CBVH_HDR_DT = np.dtype([("space", "<f4", 9), ("box", "<f4", 10), ("proj", "<f4", 9), ("rootWord", "<u4"), ("rcp_edges", "<f4"), ("extent", "<f4"), ("levels", "<u4"),
+                        ("geomID", "<u4"), ("primID", "<u4"), ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("elems", "<u4"), ("grid_width", "<u4")])
+CBVH_TAIL_DT = np.dtype([("iproj", "<f4", 9), ("wlo", "<f4", 3), ("whi", "<f4", 3), ("pad", "<f4")])
+CBVH_NODES = 160
+
+
+def cbvh_layout(C, mode):
+    """(payload offset, tail offset, stride) of a blob; mode: 'box' | 'leaf' | 'grid' | 'full'"""
+    elems = (4 ** C - 1) // 3
+    payload = (CBVH_NODES + elems * (96 if mode == "full" else 4) + 15) // 16 * 16
+    extra = 2 * 4 ** C if mode == "leaf" else (12 * (2 ** C + 1) ** 2 if mode == "grid" else 0)
+    tail = (payload + extra + 15) // 16 * 16
+    return payload, tail, (tail + 64 + 127) // 128 * 128
+
+
+def cbvh_header(blob, C, mode):
+    """all header fields of one blob (numpy uint8 row) as a dict"""
+    _, tail, _ = cbvh_layout(C, mode)
+    h = blob[:CBVH_NODES].view(CBVH_HDR_DT)[0]
+    t = blob[tail:tail + 64].view(CBVH_TAIL_DT)[0]
+    out = {k: h[k] for k in CBVH_HDR_DT.names}
+    out.update({k: t[k] for k in CBVH_TAIL_DT.names})
+    return out
+
+
 FORK_MODES = ("bvh4.compressed.box", "bvh4.compressed.leaf", "bvh4.compressed.grid", "bvh4.compressed.full")
 # oracle mode numbers (oracle/embree_oracle.h) and the modes whose result depends on the order blobs are reached in (same-tree oracle)
 FORK_ORACLE_MODE = {"default": 2, "bvh4.compressed.box": 3, "bvh4.compressed.leaf": 4, "bvh4.compressed.grid": 5, "bvh4.compressed.full": 6}

@@ -192,7 +192,7 @@ def test_subpatch_uv_windows_in_the_leaf_records(rtc):
     n = len(raw) // stride
     seen = {}
     for b in range(n):
-        h = raw[b * stride: b * stride + 24]
+        h = raw[b * stride + 128: b * stride + 152]  # ids + uv window: bytes 128.. of a blob (accel.h, CbvhMid)
         prim = int(h[4:8].view(np.uint32)[0])
         uv0 = h[8:16].view(np.float32)
         uv1 = h[16:24].view(np.float32)

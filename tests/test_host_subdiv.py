@@ -7,9 +7,7 @@ import pytest
 
 LEAF, EMPTY = 0x80000000, 0xFFFFFFFF
 CELL_DT = np.dtype([("px", "<f4", 9), ("py", "<f4", 9), ("pz", "<f4", 9), ("uv", "<u4", 9), ("geomID", "<u4"), ("primID", "<u4"), ("pad", "<u4", 2)])
-HDR_DT = np.dtype([("geomID", "<u4"), ("primID", "<u4"), ("uv0", "<f4", 2), ("uv1", "<f4", 2), ("rcp_edges", "<f4"), ("extent", "<f4"),
-                   ("elems", "<u4"), ("grid_width", "<u4"), ("levels", "<u4"), ("pad0", "<u4"),
-                   ("space", "<f4", 9), ("proj", "<f4", 9), ("iproj", "<f4", 9), ("box", "<f4", 10), ("wlo", "<f4", 3), ("whi", "<f4", 3), ("pad1", "<f4")])
+from helpers import CBVH_HDR_DT, CBVH_NODES, CBVH_TAIL_DT, cbvh_header, cbvh_layout  # noqa: E402
 T1 = np.array([0.0, 0.005, 0.01, 0.05, 0.1, 0.2, 0.4, 0.6], np.float32)  # compressed_node.h:31-38
 T2 = np.array([0.0, 0.4, 0.48, 0.49, 0.5, 0.51, 0.52, 0.6], np.float32)  # :22-29
 T3 = np.array([0.0, 0.25, 0.5, 0.75], np.float32)
@@ -33,7 +31,8 @@ def _grids(sc, L):
 
 
 def test_struct_sizes():
-    assert CELL_DT.itemsize == 160 and HDR_DT.itemsize == 224
+    assert CELL_DT.itemsize == 160 and CBVH_HDR_DT.itemsize == CBVH_NODES == 160 and CBVH_TAIL_DT.itemsize == 64
+    assert cbvh_layout(3, "leaf") == (256, 384, 512)  # line 0 | ids + nodes | cells | tail
 
 
 def test_tessellator_plane_is_reproduced_exactly(rtc):
@@ -160,15 +159,16 @@ def test_full_precision_nodes_hold_the_merged_cell_boxes(rtc, bomberman):
         dev.release()
     elems = (4 ** Cl - 1) // 3
     F, B = blobs["bvh4.compressed.full"], blobs["bvh4.compressed.box"]
-    assert F.shape[1] == (224 + 96 * elems + 15) // 16 * 16 and len(F) == len(B)
+    assert F.shape[1] == cbvh_layout(Cl, "full")[2] and B.shape[1] == cbvh_layout(Cl, "box")[2] and len(F) == len(B)
     n, sub = 2 ** L, 2 ** Cl
     rng = np.random.RandomState(1)
     for k in rng.choice(len(F), 200, replace=False):
-        H, HB = F[k][:224].view(HDR_DT)[0], B[k][:224].view(HDR_DT)[0]
+        H, HB = cbvh_header(F[k], Cl, "full"), cbvh_header(B[k], Cl, "box")
         for f in ("geomID", "primID", "uv0", "uv1", "rcp_edges", "elems", "grid_width", "levels", "space", "proj", "iproj"):
             assert np.array_equal(H[f], HB[f]), f
-        nodes = F[k][224:224 + 96 * elems].view(np.float32).reshape(elems, 6, 4)  # [node][lx ux ly uy lz uz][child]
-        words = B[k][224:224 + 4 * elems].view(np.uint32)
+        nodes = F[k][CBVH_NODES:CBVH_NODES + 96 * elems].view(np.float32).reshape(elems, 6, 4)  # [node][lx ux ly uy lz uz][child]
+        words = B[k][CBVH_NODES:CBVH_NODES + 4 * elems].view(np.uint32)
+        assert HB["rootWord"] == words[0]  # line 0 carries a copy of the root's word
         x0, y0 = int(round(H["uv0"][0] * n)), int(round(H["uv0"][1] * n))
         G = g[int(H["primID"])]
         P = np.stack([G[0][y0:y0 + sub + 1, x0:x0 + sub + 1], G[1][y0:y0 + sub + 1, x0:x0 + sub + 1], G[2][y0:y0 + sub + 1, x0:x0 + sub + 1]], -1).astype(np.float64)
@@ -229,7 +229,7 @@ def test_cbvh_encoder_is_conservative(rtc, bomberman, mode, Cl):
     rng = np.random.RandomState(0)
     worst = 0.0
     for b in blobs[rng.choice(len(blobs), 300, replace=False)]:
-        H = b[:224].view(HDR_DT)[0]
+        H = cbvh_header(b, Cl, mode.split(".")[-1])
         assert H["elems"] == elems and H["grid_width"] == sub + 1 and H["levels"] == Cl
         assert np.allclose(H["proj"].reshape(3, 3) @ H["iproj"].reshape(3, 3), np.eye(3), atol=2e-3)
         x0, y0 = int(round(H["uv0"][0] * n)), int(round(H["uv0"][1] * n))
@@ -246,7 +246,8 @@ def test_cbvh_encoder_is_conservative(rtc, bomberman, mode, Cl):
         hom = np.concatenate([loc[..., :2], np.ones(loc.shape[:2] + (1,))], -1) @ M.T
         pr = np.concatenate([hom[..., :2] / hom[..., 2:3], loc[..., 2:3]], -1)
         assert np.all(np.abs(pr[..., :2]) <= 1.0 + 1e-3)  # rescaled to the projected bounding box
-        words = b[224:224 + 4 * elems].view(np.uint32)
+        words = b[CBVH_NODES:CBVH_NODES + 4 * elems].view(np.uint32)
+        assert H["rootWord"] == words[0]
         # walk the implicit quadtree; the traversal root box is [-1,1]^2 x [box0,box1] (compressed.h:517-519)
         root = (np.array([-1, -1, H["box"][0]], np.float32), np.array([1, 1, H["box"][1]], np.float32))
         stack = [(0, root)]
