@@ -77,6 +77,8 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.exclPairs = exclPairs;
   p.exclT = exclT;
   p.overflow = sh.overflowDev;
+  static const bool timeline = getenv("RTAMD_TIMELINE") != nullptr; // development aid, see trace.h
+  p.timeline = (timeline && !dCounters) ? (unsigned long long*)sh.countersDev : nullptr;
   // {context, queue heads, launch, event} as one unit: concurrent callers on device-resident batches must not pick the same
   // context (its event still reads "finished" until the new launch has recorded it).  The stream is read once.
   std::lock_guard<std::mutex> seq(sh.seqMutex);
@@ -112,6 +114,7 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
     p.survivors = (uint32_t*)ctx.survivors;
   }
   HIP_CHECK(hipMemsetAsync(ctx.queues, 0, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, stream)); // heads, survivor counts, valid-ray counts
+  if (p.timeline) HIP_CHECK(hipMemsetAsync(p.timeline, 0, (size_t)WAVE_LOG_CAPACITY * 64, stream));
   if (p.survivors) HIP_CHECK(launch_cull(p, stream));
   HIP_CHECK(launch_trace(p, stream));
   if (cullCountsOut && p.survivors) HIP_CHECK(hipMemcpyAsync(cullCountsOut, ctx.queues, TRACE_QUEUES * TRACE_QUEUE_STRIDE * 4, hipMemcpyDeviceToHost, stream));

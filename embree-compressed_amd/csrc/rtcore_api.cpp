@@ -798,6 +798,19 @@ API const void* rtcamdGetAccelData(RTCScene h, unsigned int kind, size_t* byteSi
   return nullptr;
 }
 
+// development aid: the wave log of the last launch on the first shard (instrumented twin: WaveRecord[]; -DTRACE_TIMELINE builds with
+// RTAMD_TIMELINE=1: 8 words per wavefront of the plain kernel, trace.h), after synchronising the device
+API size_t rtcamdDebugReadWaveLog(RTCDevice hdevice, void* out, size_t bytes)
+{
+  Device* dev = (Device*)hdevice;
+  if (!dev || dev->gpu < 0 || !out) return 0;
+  Device::GpuShard& sh = dev->primary();
+  sh.use();
+  const size_t n = std::min(bytes, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord));
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, sh.countersDev, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  return n;
+}
+
 API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate)
 {
   cbvh_debug_leaf_codec(box, v, extent, bytesOut, extentEstimate);

@@ -44,6 +44,9 @@ struct LaunchParams
   // queues[q * TRACE_QUEUE_STRIDE + 2] counts the valid rays of the queue's range (for the work counters).  The traversal kernel
   // then fetches rays through the lists.  nullptr: rays are fetched by index (no pre-pass).
   uint32_t* survivors;
+  unsigned long long* timeline; // development builds (-DTRACE_TIMELINE, env RTAMD_TIMELINE=1): 8 words per wavefront of the PLAIN kernel
+                                // (start, first rays, last grab, end in 10 ns ticks; iterations, iterations after the last grab, lanes x
+                                // iterations after the last grab, rays); nullptr otherwise
   uint32_t* overflow;      // host-mapped word, set to 1 by a kernel that had to drop a traversal-stack entry (never for a tree
                            // whose depth the builder reported correctly: the overflow area is sized for the worst case)
 };

@@ -316,13 +316,15 @@ __device__ __forceinline__ bool moeller(const RayState& r, const float4 A, const
 // ---------------------------------------------------------------------------------------------------
 // ray record I/O.  RTCRayHit: [org.xyz tnear][dir.xyz time][tfar mask id flags][Ng.xyz u][v primID geomID instID]
 // ---------------------------------------------------------------------------------------------------
-// Ray records are read once and hit records written once per batch: streamed with the non-temporal hint (global_load / store ... nt),
-// so that 80 MB of rays per million do not evict the accel (BVH8 nodes + blobs) from the 4 MiB L2 of an XCD.  TRACE_RAY_NT=0: plain accesses.
+// Ray records are read once and hit records written once per batch: they COULD be streamed with the non-temporal hint (global_load /
+// store ... nt) so that 80 MB of rays per million do not evict the accel from the 4 MiB L2 of an XCD.  Measured round 3
+// (profiles/r03_layout_nt_ab.txt): nt loads make the metric kernel 2 % SLOWER alone (0.1421 -> 0.1451 ms) and 3 % in flight
+// (12.0 -> 11.66 Grays/s), nt 16-byte stores cost 12-20 B of scratch per lane at the 128-VGPR limit: plain accesses stay the default.
 #ifndef TRACE_RAY_NT
-#define TRACE_RAY_NT 1
+#define TRACE_RAY_NT 0
 #endif
 #ifndef TRACE_HIT_NT
-#define TRACE_HIT_NT 0 // (measured r3: non-temporal 16-byte hit stores cost the metric kernel 12-20 B of scratch per lane at its 128-VGPR limit; hits are 16 % of the rays)
+#define TRACE_HIT_NT 0
 #endif
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 ld_stream4(const float4* p)

@@ -172,9 +172,21 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     tBegin = tStamp = __builtin_readcyclecounter();
     rtBegin = __builtin_amdgcn_s_memrealtime();
   }
+#ifdef TRACE_TIMELINE
+  // development build: the PLAIN kernel's wave timeline (trace.h `timeline`): wave-uniform scalars only
+  unsigned long long tlBegin = 0, tlFirst = 0, tlGrab = 0;
+  uint32_t tlIter = 0, tlDrainIter = 0, tlDrainLanes = 0, tlRays = 0;
+  if (!COUNT && P.timeline) tlBegin = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (;;) {
     if (COUNT) nIter++;
+#ifdef TRACE_TIMELINE
+    if (!COUNT && P.timeline) {
+      tlIter++;
+      if (exhausted) { tlDrainIter++; tlDrainLanes += (uint32_t)__popcll(__ballot((st & ST_ACTIVE) != 0u)); }
+    }
+#endif
     // ---- refill idle lanes ---------------------------------------------------------------------------
     const uint64_t idleMask = __ballot(!(st & ST_ACTIVE));
     // refilling a handful of lanes costs as many instructions as refilling all 64: wait until refillBatch lanes are
@@ -198,6 +210,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           }
           if (base < qLen) {
             if (COUNT) rtLastGrab = __builtin_amdgcn_s_memrealtime();
+#ifdef TRACE_TIMELINE
+            if (!COUNT && P.timeline) { tlGrab = __builtin_amdgcn_s_memrealtime(); if (!tlFirst) tlFirst = tlGrab; tlRays += min(P.rayChunk, qLen - base); }
+#endif
             poolNext = qLo + base;
             poolEnd = min(poolNext + P.rayChunk, qLo + qLen);
             break;
@@ -632,6 +647,16 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     stamp(tPop);
   }
 
+#ifdef TRACE_TIMELINE
+  if (!COUNT && P.timeline) {
+    const uint32_t waveIdx = blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6);
+    if (laneId == 0u && waveIdx < WAVE_LOG_CAPACITY) {
+      unsigned long long* o = P.timeline + (size_t)waveIdx * 8u;
+      o[0] = tlBegin; o[1] = tlFirst; o[2] = tlGrab; o[3] = __builtin_amdgcn_s_memrealtime();
+      o[4] = tlIter; o[5] = tlDrainIter; o[6] = tlDrainLanes; o[7] = tlRays;
+    }
+  }
+#endif
   if (COUNT) {
     // per-lane work counters are reduced over the wave; lane 0 stores the wave's record into its own slot
     unsigned long long v[7] = {wc.rays, wc.nodes, wc.leaves, wc.prims, wc.inner, wc.hits, wc.spills};

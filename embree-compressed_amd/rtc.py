@@ -176,6 +176,7 @@ def load_library(path=LIB_PATH):
         "rtcamdOccluded1MCounted": (None, [vp, C.POINTER(RTCIntersectContext), vp, u, sz, C.POINTER(RTCAMDTraceCounters)]),
         "rtcamdGetAccelData": (vp, [vp, u, C.POINTER(sz)]),
         "rtcamdGetAccelRoot": (u, [vp]),
+        "rtcamdDebugReadWaveLog": (C.c_size_t, [vp, vp, C.c_size_t]),
         "rtcamdDebugCbvhLeafCodec": (None, [vp, vp, C.c_float, vp, C.POINTER(C.c_float)]),
         "rtcamdDebugHostPoolSelfTest": (C.c_ulonglong, [vp, u, u, u, u]),
     }

@@ -104,6 +104,8 @@ RTC_API const void* rtcamdGetAccelData(RTCScene scene, unsigned int kind, size_t
 /* Test hook: the encoder's restatement of the fork's leaf quantiser (quantTris<4>::setZ / estimateExtent,
  * kernels/geometry/compressed_leaf.h:193-251) on caller-supplied inputs: box = lower xyz, upper xyz of the parent box,
  * v = the four corner vertices (12 floats).  Lets tests compare it with the reference header compiled in oracle/_ref. */
+/* development aid: raw wave log of the last launch (csrc/trace.h `timeline`, csrc/accel.h WaveRecord) */
+RTC_API size_t rtcamdDebugReadWaveLog(RTCDevice device, void* out, size_t bytes);
 RTC_API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate);
 /* Test hook: runs `jobs` parallel jobs of `parts` parts each through the device's pool of staging threads (the pool behind the
  * chunked pipeline of large host-pointer batches; `threads` helpers are started if fewer exist), in `cycles` begin / end cycles,
