@@ -6,12 +6,25 @@
 
 namespace rtamd {
 
-uint32_t trace_grid_blocks(uint32_t count, int numCUs)
+uint32_t trace_grid_blocks(uint32_t count, int numCUs, uint32_t rayChunk)
 {
-  // upper bound of the resident set: 20 waves per CU
+  // upper bound of the resident set: 20 waves per CU; a wave takes `rayChunk` rays per queue grab
   const uint32_t resident = (uint32_t)numCUs * 5u * (256u / TRACE_BLOCK);
-  const uint32_t need = (count + TRACE_BLOCK - 1) / TRACE_BLOCK;
+  const uint32_t perBlock = std::max(1u, rayChunk) * (TRACE_BLOCK / 64u);
+  const uint32_t need = (count + perBlock - 1) / perBlock;
   return need < resident ? (need ? need : 1u) : resident;
+}
+
+// Rays a wave takes from a work queue per grab.  Large batches: Device::tuneChunk (256: one atomic per 256 rays keeps the queue heads
+// cold).  Batches that cannot give every resident wavefront (16 per CU) such a share are cut finer, down to 32 rays per wave, so that a
+// mid-size batch - a 16 k .. 128 k chunk of the host pipeline, a test batch, a combined group of small calls - spreads over the whole chip
+// instead of count / 256 wavefronts (round 3 finding, profiles/r03_deep_subset_probe.txt: 1000 rays ran on FOUR wavefronts).
+static uint32_t ray_chunk_for(const Device* dev, uint32_t M, int numCUs)
+{
+  if (dev->tuneChunkFixed) return dev->tuneChunk;
+  const uint32_t waves = (uint32_t)numCUs * 16u;
+  const uint32_t share = ((M + waves - 1u) / waves + 15u) & ~15u;
+  return std::min(dev->tuneChunk, std::max(32u, share));
 }
 
 // -1: plain host memory; otherwise the HIP ordinal the allocation lives on
@@ -45,7 +58,8 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.stride = stride;
   p.instID = instID;
   p.occluded = occluded ? 1u : 0u;
-  p.gridBlocks = trace_grid_blocks(M, sh.numCUs);
+  p.rayChunk = ray_chunk_for(dev, M, sh.numCUs);
+  p.gridBlocks = trace_grid_blocks(M, sh.numCUs, p.rayChunk);
   p.poolKernel = dev->tunePoolKernel == 2u ? (M >= dev->tunePoolMinRays ? 1u : 0u) : dev->tunePoolKernel;
   // worst-case stack: 7 siblings per level plus the entry being expanded.  The overflow area is sized for it, so a push
   // can only be dropped if the tree is deeper than the builder reported; the kernels then raise `overflow` (below).
@@ -65,7 +79,6 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   // blobs at once: one ray per lane; everything else: quad form.  RTAMD_CBVH_FORM=quad|lane overrides.
   p.cbvhLaneForm = dev->tuneCbvhForm == 2u ? (coherent ? 1u : 0u) : dev->tuneCbvhForm;
   p.numCUs = (uint32_t)sh.numCUs;
-  p.rayChunk = dev->tuneChunk;
   p.leafBatch = dev->tuneLeafBatch;
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;

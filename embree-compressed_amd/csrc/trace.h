@@ -72,7 +72,7 @@ static const int TRACE_POOL_BLOCKS_PER_CU = 8; // upper bound of resident workgr
 static const int TRACE_LDS_STACK = TRACE_LDS_STACK_ENTRIES; // stack entries per lane kept in LDS (8 bytes each -> 2 KiB per entry and workgroup)
 
 // Number of workgroups of the persistent grid for `count` rays on a chip with `numCUs` compute units.
-uint32_t trace_grid_blocks(uint32_t count, int numCUs);
+uint32_t trace_grid_blocks(uint32_t count, int numCUs, uint32_t rayChunk);
 
 // Enqueue traversal of one batch on `stream`.  Asynchronous; errors surface through the returned hipError_t.
 hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream);    // trace_tri.hip
