@@ -181,6 +181,8 @@ def load_library(path=LIB_PATH):
         "rtcamdDebugHostPoolSelfTest": (C.c_ulonglong, [vp, u, u, u, u]),
     }
     for name, (res, args) in sig.items():
+        if name.startswith("rtcamdDebug") and not hasattr(lib, name):
+            continue  # development hooks: an older build of the library (RTAMD_LIB=... in an A/B sweep) may lack the newest one
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
