@@ -279,6 +279,19 @@ def median(v):
     return w[len(w) // 2] if len(w) % 2 else 0.5 * (w[len(w) // 2 - 1] + w[len(w) // 2])
 
 
+def leaf_record_bytes(st, levels):
+    """Bytes a leaf visit is priced at in the algorithmic figure: the record's CONTENT.  Triangle records and grid cells: their size.
+    A cBVH blob: line 0 + ids / uv + node words + cells (or grid) + tail, WITHOUT the padding that rounds the round-3 stride up to a
+    multiple of 128 bytes (accel.h; C = 3 leaf mode: 448 of the 512-byte stride - the figure round 2 used for its 448-byte record)."""
+    mode = {3: "box", 4: "leaf", 5: "grid", 7: "full"}.get(st["accelKind"])
+    if mode is None:
+        return st["primBytes"]
+    C = levels[1]
+    payload = (160 + (4 ** C - 1) // 3 * (96 if mode == "full" else 4) + 15) // 16 * 16
+    extra = 2 * 4 ** C if mode == "leaf" else (12 * (2 ** C + 1) ** 2 if mode == "grid" else 0)
+    return (payload + extra + 15) // 16 * 16 + 64
+
+
 def addressed_bytes_per_ray(cnt, st, occluded, levels):
     """Second bytes figure (VERDICT r2 #2d): a leaf visit priced at the fields it READS instead of the whole padded record.
     cBVH blob (accel.h round-3 layout; counters of the instrumented twin: leafVisits = blob visits, primTests = visits that pass
@@ -401,7 +414,8 @@ def main():
                 "regionN": worstN, "region1": worst1, "kernel_ms": median(ev1), "kernel_ms_minmax": (min(ev1), max(ev1)),
                 "total_rays": total_rays, "n_node": n_node, "n_leaf": n_leaf, "n_inner": cnt["innerVisits"] / rays,
                 # implementation's own visits x record sizes; a subdiv leaf visit is priced at its whole record
-                "bytes_per_ray": io_bytes + n_node * st["nodeBytes"] + n_leaf * st["primBytes"],
+                "leaf_bytes": leaf_record_bytes(st, lv),
+                "bytes_per_ray": io_bytes + n_node * st["nodeBytes"] + n_leaf * leaf_record_bytes(st, lv),
                 "bytes_per_ray_addressed": addressed_bytes_per_ray(cnt, st, occluded, lv)}
 
     def roofline_of(R, tag, traffic, traffic_src, with_profiles):
@@ -413,7 +427,7 @@ def main():
                 "kernel_us_rocprofv3": rocprof_kernel_us(tag, traffic_src) if with_profiles else None,
                 "aggregate_frac_in_flight": R["bytes_per_ray"] * R["m"] * R["K"] / med / 1e9 / HBM_PEAK_GBS,
                 "bytes_per_ray": R["bytes_per_ray"], "nodes_per_ray": R["n_node"], "leaf_visits_per_ray": R["n_leaf"],
-                "inner_steps_per_ray": R["n_inner"], "node_bytes": R["st"]["nodeBytes"], "leaf_bytes": R["st"]["primBytes"],
+                "inner_steps_per_ray": R["n_inner"], "node_bytes": R["st"]["nodeBytes"], "leaf_bytes": R["leaf_bytes"], "leaf_stride_bytes": R["st"]["primBytes"],
                 "bytes_per_ray_addressed": R["bytes_per_ray_addressed"],
                 "frac_addressed": R["bytes_per_ray_addressed"] * R["m"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_note": "achieved / frac price ALGORITHMIC bytes (SURVEY.md 8d: every node / leaf record a ray visits, L1 / L2 hits "

@@ -40,25 +40,32 @@ void Device::parse(const std::string& cfg)
     else if (key == "gpu" || key == "device") { gpu = (val == "none") ? -1 : atoi(val.c_str()); gpuList.clear(); }
     else if (key == "gpus") {
       // "gpus=0-7" (range), "gpus=0:2:5" (list; ',' separates config keys), "gpus=0:0" (two logical shards on one GPU)
+      // malformed input is an error, not a silent fall-back to gpu=0: empty list, inverted range, non-numeric token, > 64 shards
       gpuList.clear();
+      auto number = [](const std::string& t) { return !t.empty() && t.find_first_not_of("0123456789") == std::string::npos; };
       size_t a = 0;
       while (a <= val.size()) {
         size_t b = val.find(':', a);
         if (b == std::string::npos) b = val.size();
         const std::string tok = val.substr(a, b - a);
         const size_t dash = tok.find('-');
-        if (!tok.empty()) {
-          if (dash != std::string::npos && dash > 0) {
-            const int lo = atoi(tok.substr(0, dash).c_str()), hi = atoi(tok.substr(dash + 1).c_str());
-            for (int g = lo; g <= hi && gpuList.size() < 64; g++) gpuList.push_back(g);
-          } else
-            gpuList.push_back(atoi(tok.c_str()));
+        if (dash != std::string::npos) {
+          const std::string sl = tok.substr(0, dash), sh = tok.substr(dash + 1);
+          if (!number(sl) || !number(sh)) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpus=: malformed range '" + tok + "'");
+          const int lo = atoi(sl.c_str()), hi = atoi(sh.c_str());
+          if (hi < lo) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpus=: inverted range '" + tok + "'");
+          for (int g = lo; g <= hi; g++) gpuList.push_back(g);
+        } else {
+          if (!number(tok)) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpus=: malformed entry '" + tok + "'");
+          gpuList.push_back(atoi(tok.c_str()));
         }
+        if (gpuList.size() > 64) RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "gpus=: more than 64 shards");
         a = b + 1;
       }
-      if (!gpuList.empty()) gpu = gpuList[0];
+      gpu = gpuList[0];
     }
     else if (key == "threads") numThreads = atoi(val.c_str());
+    else if (key == "host_threads") tuneHostThreads = (uint32_t)std::max(0, atoi(val.c_str())); // staging threads of pipelined host batches (also env RTAMD_HOST_THREADS)
     else if (key == "benchmark") benchmark = atoi(val.c_str());
     else if (key == "keep_grids") keepGrids = atoi(val.c_str());
     // isa, max_isa, set_affinity, affinity, start_threads, hugepages, float_exceptions, ... : x86-only, ignored
@@ -272,6 +279,18 @@ Device::LaunchCtx& Device::GpuShard::acquireLaunchCtx(size_t spillBytesNeeded, u
 }
 
 // ---- HostPool ----------------------------------------------------------------------------------------
+// One step of a polling loop: the CPU's spin hint, and after a while a yield, so that a helper (or the caller) that lost its core to
+// the application's own threads does not keep another one busy for nothing
+static inline void spin_relax(unsigned& spins)
+{
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield");
+#endif
+  if (++spins >= 4096u) { std::this_thread::yield(); spins = 0; }
+}
+
 bool Device::HostPool::take(uint64_t gen, size_t n, size_t& i)
 {
   uint64_t t = ticket.load(std::memory_order_acquire);
@@ -292,10 +311,12 @@ void Device::HostPool::start(unsigned n)
           cv.wait(lk, [this] { return stop.load() || hot.load(); });
           if (stop.load()) return;
         }
+        unsigned spins = 0;
         while (hot.load(std::memory_order_acquire)) {
           const uint64_t g = ticket.load(std::memory_order_acquire) >> 32;
-          if (g == seen) { __builtin_ia32_pause(); continue; }
+          if (g == seen) { spin_relax(spins); continue; }
           seen = g;
+          spins = 0;
           const std::function<void(size_t)>* f = job.load(std::memory_order_relaxed); // written before the ticket of generation g was published
           const size_t n = nParts.load(std::memory_order_relaxed);
           size_t i;
@@ -332,7 +353,8 @@ void Device::HostPool::run(size_t parts, const std::function<void(size_t)>& f)
     f(i);
     done.fetch_add(1, std::memory_order_acq_rel);
   }
-  while (done.load(std::memory_order_acquire) < parts) __builtin_ia32_pause();
+  unsigned spins = 0;
+  while (done.load(std::memory_order_acquire) < parts) spin_relax(spins);
 }
 
 Device::HostPool::~HostPool()

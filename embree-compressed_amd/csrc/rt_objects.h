@@ -145,6 +145,7 @@ struct Device : RefCounted
   std::condition_variable combCv;
   std::vector<SmallCall*> combPending;
   bool combBusy = false;
+  std::atomic<bool> combHold{false}; // test hook: rtcamdDebugHoldCombiner
   std::atomic<uint64_t> statLaunches{0};      // traversal kernel launches
   std::atomic<uint64_t> statCombinedCalls{0}; // calls that went through the combiner
   std::atomic<uint64_t> statCombinedBatches{0}; // batches the combiner formed out of them

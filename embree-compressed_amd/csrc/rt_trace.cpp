@@ -19,6 +19,10 @@ uint32_t trace_grid_blocks(uint32_t count, int numCUs, uint32_t rayChunk)
 // cold).  Batches that cannot give every resident wavefront (16 per CU) such a share are cut finer, down to 32 rays per wave, so that a
 // mid-size batch - a 16 k .. 128 k chunk of the host pipeline, a test batch, a combined group of small calls - spreads over the whole chip
 // instead of count / 256 wavefronts (round 3 finding, profiles/r03_deep_subset_probe.txt: 1000 rays ran on FOUR wavefronts).
+// With other batches in flight the coarse share wins again from ~100 k rays on (every wavefront pays its deepest ray's iterations, the chip
+// is issue bound: fewer, fuller wavefronts per batch), so launch_on switches back to tuneChunk there.  Measured round 3, cbvh.leaf, kernel
+// alone / four batches in flight, fine vs 256-ray chunks (profiles/r03_chunk_ab.txt): 4 k rays 43 vs 105 us / 222 vs 105 Mrays/s, 16 k 46 vs
+// 89 us / 779 vs 525, 64 k 61 vs 98 us / 1.90 vs 1.84 Grays/s, 128 k 73 vs 98 us / 2.97 vs 3.52, 250 k 104 vs 107 us / 4.8 vs 5.7, 500 k 0 % / -7 %.
 static uint32_t ray_chunk_for(const Device* dev, uint32_t M, int numCUs)
 {
   if (dev->tuneChunkFixed) return dev->tuneChunk;
@@ -110,6 +114,10 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   // 13.3 -> 13.8 Grays/s, shadow rays 9.3 -> 9.8, camera rays 7.1 -> 7.7)
   const uint32_t busyBlocks = octOnly ? dev->tuneBusyBlocksOct : 1u;
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? busyBlocks : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
+  if (busyOther >= 1u && M >= 100000u && !dev->tuneChunkFixed && p.rayChunk < dev->tuneChunk && !p.poolKernel) {
+    p.rayChunk = dev->tuneChunk; // in flight: coarse shares (see ray_chunk_for); the grid only shrinks, the overflow area was sized for the larger one
+    p.gridBlocks = trace_grid_blocks(M, sh.numCUs, p.rayChunk);
+  }
   p.queues = (uint32_t*)ctx.queues;
   // Root cull pre-pass (trace_cull.hip.h): large batches on the lane kernel whose root is an inner node.  Filter re-traces
   // (exclusion lists) are small and skip it.
@@ -659,12 +667,17 @@ void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlud
   call.stride = byteStride;
   call.occluded = occluded;
   call.instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
-  dev->statCombinedCalls++;
   std::unique_lock<std::mutex> lk(dev->combMutex);
   dev->combPending.push_back(&call);
+  dev->statCombinedCalls++; // counted once the call is pending (the held-leader test waits on this count)
   while (!call.done) {
     if (!dev->combBusy) { // become the leader for everything that is pending now (own call included)
       dev->combBusy = true;
+      while (dev->combHold.load(std::memory_order_acquire)) { // test hook (rtcamdDebugHoldCombiner): the leader waits, the others queue up behind it
+        lk.unlock();
+        std::this_thread::yield();
+        lk.lock();
+      }
       std::vector<Device::SmallCall*> batch;
       batch.swap(dev->combPending);
       lk.unlock();

@@ -700,7 +700,13 @@ API void rtcReleaseBVH(RTCBVH) { CATCH_BEGIN unsupported("rtcReleaseBVH"); CATCH
 // ---- MI355X extensions (include/embree3/rtcore_amd.h) -------------------------------------------------------------------
 API void* rtcamdGetDeviceStream(RTCDevice h)
 {
-  CATCH_BEGIN VERIFY(h); D(h)->useDevice(); return (void*)D(h)->primary().stream; CATCH_END(D(h))
+  CATCH_BEGIN
+  VERIFY(h);
+  D(h)->useDevice();
+  Device::GpuShard& sh = D(h)->primary();
+  std::lock_guard<std::mutex> seq(sh.seqMutex); // launches read the stream under this mutex (rt_trace.cpp launch_on)
+  return (void*)sh.stream;
+  CATCH_END(D(h))
   return nullptr;
 }
 
@@ -712,13 +718,21 @@ API void rtcamdSetDeviceStream(RTCDevice h, void* stream)
   d->useDevice();
   // the stream of the FIRST shard: device-resident batches are traced on the GPU they live on, and a caller that manages
   // streams itself works with one GPU per RTCDevice (one process per GPU)
+  // The stream is one mutable value per device: a launch reads it under the shard's seqMutex, so switching it is serialised with
+  // launches here; two threads that want DIFFERENT streams at the same time still have to order their
+  // {rtcamdSetDeviceStream, rtcIntersect1M} pairs themselves (or use one RTCDevice per thread).
   Device::GpuShard& sh = d->primary();
-  if (sh.stream && sh.ownsStream) {
-    HIP_CHECK(hipStreamSynchronize(sh.stream));
-    HIP_CHECK(hipStreamDestroy(sh.stream));
+  hipStream_t old = nullptr;
+  {
+    std::lock_guard<std::mutex> seq(sh.seqMutex);
+    if (sh.stream && sh.ownsStream) old = sh.stream;
+    sh.stream = (hipStream_t)stream;
+    sh.ownsStream = false;
   }
-  sh.stream = (hipStream_t)stream;
-  sh.ownsStream = false;
+  if (old) { // the library's own stream: drained and destroyed outside the lock, nobody can pick it up any more
+    HIP_CHECK(hipStreamSynchronize(old));
+    HIP_CHECK(hipStreamDestroy(old));
+  }
   CATCH_END(D(h))
 }
 
@@ -809,6 +823,14 @@ API size_t rtcamdDebugReadWaveLog(RTCDevice hdevice, void* out, size_t bytes)
   const size_t n = std::min(bytes, 2 * (size_t)WAVE_LOG_CAPACITY * sizeof(WaveRecord));
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, sh.countersDev, n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   return n;
+}
+
+// test hook: while `hold` is non-zero the call combiner's leader waits before it collects the pending calls, so that a test can make
+// calls from several threads meet in ONE combined batch deterministically (tests/test_gpu_small_calls.py)
+API void rtcamdDebugHoldCombiner(RTCDevice hdevice, int hold)
+{
+  Device* dev = (Device*)hdevice;
+  if (dev) dev->combHold.store(hold != 0, std::memory_order_release);
 }
 
 API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate)

@@ -177,6 +177,7 @@ def load_library(path=LIB_PATH):
         "rtcamdGetAccelData": (vp, [vp, u, C.POINTER(sz)]),
         "rtcamdGetAccelRoot": (u, [vp]),
         "rtcamdDebugReadWaveLog": (C.c_size_t, [vp, vp, C.c_size_t]),
+        "rtcamdDebugHoldCombiner": (None, [vp, C.c_int]),
         "rtcamdDebugCbvhLeafCodec": (None, [vp, vp, C.c_float, vp, C.POINTER(C.c_float)]),
         "rtcamdDebugHostPoolSelfTest": (C.c_ulonglong, [vp, u, u, u, u]),
     }

@@ -106,6 +106,8 @@ RTC_API const void* rtcamdGetAccelData(RTCScene scene, unsigned int kind, size_t
  * v = the four corner vertices (12 floats).  Lets tests compare it with the reference header compiled in oracle/_ref. */
 /* development aid: raw wave log of the last launch (csrc/trace.h `timeline`, csrc/accel.h WaveRecord) */
 RTC_API size_t rtcamdDebugReadWaveLog(RTCDevice device, void* out, size_t bytes);
+/* test hook: hold (1) / release (0) the leader of the small-call combiner */
+RTC_API void rtcamdDebugHoldCombiner(RTCDevice device, int hold);
 RTC_API void rtcamdDebugCbvhLeafCodec(const float* box, const float* v, float extent, unsigned char* bytesOut, float* extentEstimate);
 /* Test hook: runs `jobs` parallel jobs of `parts` parts each through the device's pool of staging threads (the pool behind the
  * chunked pipeline of large host-pointer batches; `threads` helpers are started if fewer exist), in `cycles` begin / end cycles,

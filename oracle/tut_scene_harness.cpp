@@ -9,7 +9,7 @@
 // refers to (tutorial.cpp:45-74, pathtracer.cpp:21-24) and starts the reference's internal task scheduler.
 //
 //   tut_<name> <cfg> <width> <height> <out.raw> <scene.obj> fromx fromy fromz tox toy toz fov subdivLevel compressionLevel [spp [threads]]
-// With spp given (pathtracer) an ambient and a directional light are added the way `--ambientlight 0.6 0.6 0.6 --directionallight -1 -1 -1 2 2 2`
+// With spp given (pathtracer) an ambient and a directional light are added the way `--ambientlight 0.15 0.15 0.15 --directionallight -1 -1 -1 0.6 0.6 0.6`
 // does (tutorial.cpp:413-430); threads = host threads of the tutorial's task scheduler (default: all).
 #include "tutorials/common/tutorial/tutorial_device.h"
 #include "tutorials/common/tutorial/scene_device.h"
@@ -84,8 +84,8 @@ int main(int argc, char** argv)
     Ref<SceneGraph::GroupNode> scene = new SceneGraph::GroupNode;
     scene->add(loadOBJ(FileName(argv[5]), true));
     if (argc > 15) { // tutorial.cpp:413-430
-      scene->add(new SceneGraph::LightNode(new SceneGraph::AmbientLight(Vec3fa(0.6f, 0.6f, 0.6f))));
-      scene->add(new SceneGraph::LightNode(new SceneGraph::DirectionalLight(Vec3fa(-1.f, -1.f, -1.f), Vec3fa(2.f, 2.f, 2.f))));
+      scene->add(new SceneGraph::LightNode(new SceneGraph::AmbientLight(Vec3fa(0.15f, 0.15f, 0.15f))));
+      scene->add(new SceneGraph::LightNode(new SceneGraph::DirectionalLight(Vec3fa(-1.f, -1.f, -1.f), Vec3fa(0.6f, 0.6f, 0.6f))));
     }
     TutorialScene obj_scene;
     obj_scene.add(SceneGraph::flatten(scene, SceneGraph::INSTANCING_NONE));

@@ -103,7 +103,7 @@ def test_pathtracer_tutorial_frame(rtc, bomberman, tmp_path, accel):
     assert np.array_equal(img_mt, img_1t), int((img_mt != img_1t).sum())
     ch = _channels(img_mt)
     lum = ch.sum(-1)
-    assert (lum > 0).mean() > 0.9 and len(np.unique(lum)) > 50  # lit by the ambient + directional light of the harness, not flat
+    assert (lum > 0).mean() > 0.9 and len(np.unique(lum)) > 30  # lit by the ambient + directional light of the harness, not flat
     # primary visibility: pixels that see geometry (rtcIntersect1M on the pixel centres) are darker than the ambient background on average
     rg = importlib.import_module("embree-compressed_amd.raygen")
     verts, fs, fi = bomberman

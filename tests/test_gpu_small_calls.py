@@ -68,6 +68,56 @@ def test_concurrent_single_ray_calls_are_combined_and_exact(rtc, po, bomberman):
     dev.release()
 
 
+def test_held_leader_combines_all_pending_calls_into_one_launch(rtc, bomberman):
+    """Deterministic check of the combiner: the leader is held (rtcamdDebugHoldCombiner) until T single-ray calls from T
+    threads are pending, then released: the T calls must be traced as ONE batch - one kernel launch - and every caller gets its
+    own result, identical to one rtcIntersect1M over the same rays."""
+    import threading
+    import time
+    verts, fs, fi = bomberman
+    dev = rtc.Device("tri_accel=bvh8.triangle4v")
+    sc = rtc.Scene(dev)
+    sc.add_triangles(verts, rtc.fan_triangulate(fs, fi))
+    sc.commit()
+    T = 12
+    rg = __import__("importlib").import_module("embree-compressed_amd.raygen")
+    src = rg.make_random_rays(T, verts.min(0), verts.max(0), seed=5).reshape(-1).view(rtc.RAYHIT_DTYPE)
+    want = rtc.aligned_rayhits(T)
+    want[:] = src
+    sc.intersect1M(want)
+    got = rtc.aligned_rayhits(T)
+    got[:] = src
+    calls0 = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS)
+    launches0 = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES)
+    lib = rtc.lib()
+    lib.rtcamdDebugHoldCombiner(dev.handle, 1)
+    errors = []
+
+    def worker(i):
+        try:
+            sc.intersect1(got[i:i + 1])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
+    for th in threads:
+        th.start()
+    deadline = time.time() + 30
+    while dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS) - calls0 < T and time.time() < deadline:
+        time.sleep(0.001)
+    queued = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS) - calls0
+    lib.rtcamdDebugHoldCombiner(dev.handle, 0)
+    for th in threads:
+        th.join()
+    assert not errors, errors[0]
+    assert queued == T
+    launches = dev.get_property(rtc.RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES) - launches0
+    assert launches == 1, (launches, T)  # a call is counted once it is pending: all T were, when the leader was released
+    assert got.tobytes() == want.tobytes()
+    sc.release()
+    dev.release()
+
+
 def test_error_of_a_combined_call_reaches_its_caller(rtc):
     dev = rtc.Device("")
     sc = rtc.Scene(dev)

@@ -14,7 +14,13 @@ if [ "$SQP_SETS" = mem ]; then
         "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_MULTI_MISS_sum"
         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum"
         "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_sum"
-        "TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum")
+        "TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+        "TA_BUSY_avr")
+  # round 2 had the derived metric TA_BUSY_avr (an average over the TA instances) in ONE pass with three raw TA_*_sum counters: rocprofv3 aborted
+  # with signal 6 in that pass (profiles/r02_cbvh_leaf_sq_stalls.txt).  The derived metric now has a pass of its own; the names offered by the
+  # box are recorded first (rocprofv3 --list-avail), and a pass that fails is reported with the end of its log and the sweep goes on.
+  (rocprofv3 --list-avail 2>/dev/null | grep -oE "TA_(BUSY|TOTAL_WAVEFRONTS|ADDR_STALLED_BY_TC_CYCLES|DATA_STALLED_BY_TC_CYCLES)[A-Za-z_]*" | sort -u | tr "\n" " "; echo) > $O/ta_counters_available.txt
+  echo "# TA counters offered by rocprofv3 --list-avail on this box: $(cat $O/ta_counters_available.txt)" >> $O/summary.txt
 else
   SETS=("SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES"
         "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM"
@@ -26,7 +32,12 @@ fi
 for set in "${SETS[@]}"; do
   i=$((i+1))
   echo "== pass $i: $set" >> $O/summary.txt
-  timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -- python3 $R/bench.py --workload $W "$@" --inflight 1 --steps 6 --warmup 2 --cpu-seconds 0 --no-others > $O/log_$i.txt 2>&1 || { echo "pass failed" >> $O/summary.txt; tail -n 3 $O/log_$i.txt >> $O/summary.txt; exit 1; }
-  python3 $R/tools/sq_summary.py $O/p$i >> $O/summary.txt
+  if timeout -k 10 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -- python3 $R/bench.py --workload $W "$@" --inflight 1 --steps 6 --warmup 2 --repeats 1 --cpu-seconds 0 --no-others --no-pcie --scaled-levels none > $O/log_$i.txt 2>&1; then
+    python3 $R/tools/sq_summary.py $O/p$i >> $O/summary.txt
+  else
+    echo "pass failed (rc $?); end of its log (kept whole as log_$i.txt next to this file):" >> $O/summary.txt
+    tail -n 15 $O/log_$i.txt | cut -c1-300 >> $O/summary.txt
+  fi
+  rm -rf $O/p$i
 done
 cat $O/summary.txt
