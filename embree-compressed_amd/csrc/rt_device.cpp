@@ -76,7 +76,6 @@ Device::Device(const char* cfg)
 {
   if (const char* env = getenv("RTAMD_GPU")) gpu = atoi(env);
   if (const char* env = getenv("RTAMD_CHUNK")) { tuneChunk = (uint32_t)std::max(1, atoi(env)); tuneChunkFixed = true; }
-  if (const char* env = getenv("RTAMD_ADOPT")) tuneAdopt = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_LEAF_BATCH")) tuneLeafBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_REFILL_BATCH")) tuneRefillBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_LEAF")) tuneOctLeaf = (uint32_t)std::max(0, atoi(env));

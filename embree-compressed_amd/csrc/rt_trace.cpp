@@ -118,9 +118,6 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
     p.rayChunk = dev->tuneChunk; // in flight: coarse shares (see ray_chunk_for); the grid only shrinks, the overflow area was sized for the larger one
     p.gridBlocks = trace_grid_blocks(M, sh.numCUs, p.rayChunk);
   }
-  // drain spreading (trace_loop.hip.h): only for a batch alone on the chip - a wavefront that waits for a sibling's ray keeps a slot another
-  // batch's wavefronts could use
-  p.adopt = (dev->tuneAdopt && busyOther == 0u && !dCounters && !p.poolKernel) ? 1u : 0u;
   p.queues = (uint32_t*)ctx.queues;
   // Root cull pre-pass (trace_cull.hip.h): large batches on the lane kernel whose root is an inner node.  Filter re-traces
   // (exclusion lists) are small and skip it.

@@ -37,7 +37,6 @@ struct LaunchParams
   const uint32_t* exclOffsets;
   const uint2* exclPairs;
   const uint32_t* exclT;
-  uint32_t adopt;          // 1: wavefronts that run out of work adopt rays of their workgroup's draining siblings (trace_loop.hip.h "drain spreading"; a batch alone on the chip)
   uint32_t poolKernel;     // 1: ray-pool skeleton (trace_pool.hip.h), 0: lane-per-ray skeleton (trace_loop.hip.h)
   // Root cull pass (trace_cull.hip.h): when `survivors` is set, a streaming pre-pass has tested every ray against the root node's
   // children and appended the indices of the rays that hit at least one of them to per-work-queue lists: queue q's list starts

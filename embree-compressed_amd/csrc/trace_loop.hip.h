@@ -79,27 +79,9 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
-// ---- drain spreading ("adoption", round 3) ------------------------------------------------------------------------
-// tools/timeline_probe.py: from ~60 % of a batch's duration on, most workgroups have ONE wavefront left, holding a handful of deep rays,
-// while its three siblings have exited.  Every iteration of that wave runs a node pass AND a blob pass (its rays are in both states),
-// so each ray advances one step per ~2.7 us although its own step takes 1.1 us (node) or 1.2-3 us (blob).  With P.adopt set (a batch
-// alone on the chip, closest-hit kernels whose hit lives in the ray record) a wave that runs out of work does not exit: it offers
-// itself in an LDS mailbox, and a sibling that still has two or more rays hands one over per iteration - ray index, current node,
-// stack pointer, tfar; the stack entries are copied from the donor lane's LDS column, the ray is re-read from its record.  The ray's
-// own sequence of operations is untouched (same node, same stack, same tfar), so results are byte-identical; only which wavefront
-// executes the steps changes.  Protocol (all in LDS, workgroup scope): word 0 = mask of waves asking for a ray; a donor claims an
-// asker with atomicAnd (one winner), then fills box[asker] and sets its state word; an asker leaves only after withdrawing its bit
-// with atomicAnd - if a donor got there first it waits for the box instead.  Every loop is bounded; an asker also leaves when no
-// sibling has two rays left (ray counts only fall, except 0 -> 1 by adoption).
-enum : int { ADOPT_WANT = 0, ADOPT_STATUS = 4, ADOPT_BOX = 8, ADOPT_BOX_WORDS = 8, ADOPT_WORDS = ADOPT_BOX + (TRACE_BLOCK / 64) * ADOPT_BOX_WORDS };
-#ifndef TRACE_ADOPT_POLLS
-#define TRACE_ADOPT_POLLS 1500u
-#endif
-
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
-__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK], float (*octX)[OCT_WORDS], uint32_t* adoptLds)
+__device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK], float (*octX)[OCT_WORDS])
 {
-  constexpr bool ADOPT = Leaf::HIT_IN_MEMORY && !OCCLUDED && !COUNT; // the hit is in the ray record already: four words describe a ray in flight
   const uint32_t tid = threadIdx.x;
   const uint32_t gthread = blockIdx.x * TRACE_BLOCK + tid;
   // overflow column of this lane in the HBM spill area: formed where it is used (rare path) from an opaque copy of the thread
@@ -268,97 +250,14 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         poolNext = min(poolNext + (uint32_t)__popcll(idleMask), poolEnd);
       }
     }
-    if constexpr (ADOPT) {
-      if (P.adopt && exhausted) {
-        const uint32_t myWave = tid >> 6;
-        const uint64_t act = __ballot((st & ST_ACTIVE) != 0u);
-        if (laneId == 0u) __hip_atomic_store(&adoptLds[ADOPT_STATUS + myWave], (uint32_t)__popcll(act), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // hand ONE ray to an asking sibling: never lane 0's (adopters work in their lane 0 and copy into its stack column), never one whose
-        // stack reaches into the HBM overflow area
-        const uint64_t cand = __ballot(st == ST_ACTIVE && laneId != 0u && sp <= (uint32_t)TRACE_LDS_STACK);
-        if (__popcll(act) >= 2 && cand != 0ull) {
-          const uint32_t want = __hip_atomic_load(&adoptLds[ADOPT_WANT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & ~(1u << myWave);
-          if (want != 0u) {
-            const uint32_t a = (uint32_t)__ffs(want) - 1u;
-            const uint32_t d = 63u - (uint32_t)__clzll(cand);
-            if (laneId == d) {
-              const uint32_t old = __hip_atomic_fetch_and(&adoptLds[ADOPT_WANT], ~(1u << a), __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (old & (1u << a)) { // this lane won the asker: its hit stores are complete before the box is published
-                uint32_t* box = adoptLds + ADOPT_BOX + a * ADOPT_BOX_WORDS;
-                box[1] = rayIdx; box[2] = cur; box[3] = sp; box[4] = __float_as_uint(r.tfar); box[5] = tid; box[6] = r.hit;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __hip_atomic_store(&box[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                st = 0u;
-              }
-            }
-          }
-        }
-      }
-    }
     stamp(tFetch);
     if (COUNT) {
       laneIters += (unsigned long long)__popcll(__ballot((st & ST_ACTIVE) != 0u));
       if (st & ST_ACTIVE) { raySteps++; maxRaySteps = max(maxRaySteps, raySteps); }
     }
     if (__ballot((st & ST_ACTIVE) != 0u) == 0ull) {
-      if (!exhausted) continue;
-      bool adopted = false;
-      if constexpr (ADOPT) {
-        if (P.adopt) {
-          const uint32_t myWave = tid >> 6, bit = 1u << myWave;
-          uint32_t* box = adoptLds + ADOPT_BOX + myWave * ADOPT_BOX_WORDS;
-          if (laneId == 0u) {
-            __hip_atomic_store(&adoptLds[ADOPT_STATUS + myWave], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_or(&adoptLds[ADOPT_WANT], bit, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          uint32_t full = 0u;
-          for (uint32_t poll = 0; poll < TRACE_ADOPT_POLLS; poll++) {
-            full = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&box[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (full) break;
-            // can a sibling still spare a ray?  (0xFFFF = still fetching from the queues)
-            uint32_t most = 0u;
-#pragma unroll
-            for (uint32_t w = 0; w < (uint32_t)(TRACE_BLOCK / 64); w++)
-              most = max(most, w == myWave ? 0u : __hip_atomic_load(&adoptLds[ADOPT_STATUS + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            if (__builtin_amdgcn_readfirstlane(most) < 2u) break;
-            __builtin_amdgcn_s_sleep(2);
-          }
-          if (!full) { // withdraw the request; if a donor has claimed it in the meantime its ray is on the way
-            uint32_t old = 0u;
-            if (laneId == 0u) old = __hip_atomic_fetch_and(&adoptLds[ADOPT_WANT], ~bit, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if (!(old & bit)) {
-              for (uint32_t poll = 0; poll < (1u << 22) && !full; poll++) {
-                full = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&box[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-                if (!full) __builtin_amdgcn_s_sleep(1);
-              }
-              if (!full) __hip_atomic_store(P.overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // cannot happen: the donor publishes right after its claim; reported as an error if it ever does
-            }
-          }
-          if (full) {
-            const uint32_t aIdx = box[1], aCur = box[2], aSp = box[3], aFar = box[4], aTid = box[5], aHit = box[6];
-            // the donor's stack entries, lane e copies entry e; then the box is free again
-            if (laneId < aSp) ldsStack[laneId][tid - laneId] = ldsStack[laneId][aTid];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            if (laneId == 0u) {
-              __hip_atomic_store(&box[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-              rayIdx = aIdx;
-              load_ray<VEC>((const char*)P.rays + (size_t)rayIdx * P.stride, r);
-              r.tfar = __uint_as_float(aFar);
-              r.hit = aHit;
-              tr.init(r);
-              travFar = r.tfar; // closest hit: tray.tfar follows ray.tfar (fmaxf(tfar, 0) = tfar for a ray that is in flight)
-              sp = aSp;
-              cur = aCur;
-              st = ST_ACTIVE;
-            }
-            adopted = true;
-          }
-        }
-      }
-      if (adopted) continue;
-      break;
+      if (exhausted) break;
+      continue;
     }
 
     // ---- inner node step ---------------------------------------------------------------------------------
@@ -798,11 +697,8 @@ __global__ __launch_bounds__(TRACE_BLOCK, COUNT ? TRACE_COUNT_MIN_WAVES(Leaf) : 
 {
   __shared__ uint2 ldsStack[TRACE_LDS_STACK + 1][TRACE_BLOCK]; // + one scratch row for the branch-free pushes
   __shared__ __attribute__((aligned(16))) float octX[TRACE_BLOCK / 64][OCT_ROWS][OCT_WORDS]; // octet node step: per-wave exchange rows
-  __shared__ uint32_t adoptLds[ADOPT_WORDS]; // drain spreading mailbox (see trace_body)
-  if (threadIdx.x < (uint32_t)ADOPT_WORDS) adoptLds[threadIdx.x] = (threadIdx.x >= (uint32_t)ADOPT_STATUS && threadIdx.x < (uint32_t)ADOPT_BOX) ? 0xFFFFu : 0u;
   Leaf::prepare();
-  __syncthreads();
-  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack, octX[threadIdx.x >> 6], adoptLds);
+  trace_body<Leaf, ROBUST, OCCLUDED, COUNT, VEC>(P, ldsStack, octX[threadIdx.x >> 6]);
 }
 
 template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT>

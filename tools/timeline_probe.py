@@ -28,7 +28,7 @@ for k in range(6):
     t0 = w[:, 0].min()
     us = lambda a: (a.astype(np.int64) - int(t0)) / 100.0
     begin, first, grab, end = us(w[:, 0]), us(w[:, 1]), us(w[:, 2]), us(w[:, 3])
-    it, dit, dl, rays = w[:, 4].astype(np.int64), w[:, 5].astype(np.int64), w[:, 6].astype(np.int64), w[:, 7].astype(np.int64)
+    it, dit, dl, rays, adopt = w[:, 4].astype(np.int64), w[:, 5].astype(np.int64), w[:, 6].astype(np.int64), (w[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.int64), (w[:, 7] >> np.uint64(32)).astype(np.int64)
     print('launch %d: %.1f us by events; %d waves; rays handed out %d' % (k, e0.elapsed_time(e1) * 1e3, len(w), rays.sum()))
     print('  wave start   : min %.1f  median %.1f  max %.1f us' % (begin.min(), np.median(begin), begin.max()))
     print('  last grab    : min %.1f  median %.1f  max %.1f us (waves with rays: %d)' % (grab[rays > 0].min(), np.median(grab[rays > 0]), grab[rays > 0].max(), (rays > 0).sum()))
@@ -37,6 +37,7 @@ for k in range(6):
     busy = (grab - first)[rays > 0]; drain = (end - grab)[rays > 0]
     print('  per wave     : first rays -> last grab %.1f us, last grab -> end %.1f us (max %.1f); us per iteration overall %.2f, in the drain %.2f' % (
         busy.mean(), drain.mean(), drain.max(), ((end - first)[rays > 0] / np.maximum(it[rays > 0], 1)).mean(), (drain / np.maximum(dit[rays > 0], 1)).mean()))
+    print('  adoptions    : %d rays adopted by %d waves (max %d per wave)' % (adopt.sum(), (adopt > 0).sum(), adopt.max()))
     hist, edges = np.histogram(end, bins=np.arange(0, end.max() + 10, 10))
     alive = len(w) - np.cumsum(hist)
     print('  waves alive at t (10 us steps): ' + ' '.join('%d' % a for a in np.concatenate([[len(w)], alive])))
