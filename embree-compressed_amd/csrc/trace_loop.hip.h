@@ -327,7 +327,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
               const float tN = fmaxf(t.nearT(npx, npy, npz), t.tnear);
               const float tF = fminf(t.farT(fpx, fpy, fpz), oFar);
               const bool h = (tN <= tF) & (cref != REF_EMPTY);
-              const uint32_t dist = h ? __float_as_uint(tN) : 0xFFFFFFFFu;
+              const uint32_t dist = h ? __float_as_uint(tN) : 0x7FFFFFFFu; // non-hit: above every distance, below 2^31 (the ranking takes the sign of differences)
               // all 8 lanes of an octet are in here together (`done` is uniform within the octet), so the ballot bits and
               // the DPP partners of a lane are always live
               const uint32_t mask8 = (uint32_t)(__ballot(h) >> (lid & 56u)) & 0xffu;
@@ -341,14 +341,14 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
                 const uint32_t m = dpp_u32<DPP_HALF_MIRROR>(dist); // child k^7
                 const uint32_t d1 = dpp_u32<DPP_XOR1>(dist), d2 = dpp_u32<DPP_XOR2>(dist), d3 = dpp_u32<DPP_XOR3>(dist);
                 const uint32_t d4 = dpp_u32<DPP_XOR3>(m), d5 = dpp_u32<DPP_XOR2>(m), d6 = dpp_u32<DPP_XOR1>(m);
-                rank = 0;
-                rank += d1 < dist + ((k ^ 1u) > k ? 1u : 0u) ? 1u : 0u;
-                rank += d2 < dist + ((k ^ 2u) > k ? 1u : 0u) ? 1u : 0u;
-                rank += d3 < dist + ((k ^ 3u) > k ? 1u : 0u) ? 1u : 0u;
-                rank += d4 < dist + ((k ^ 4u) > k ? 1u : 0u) ? 1u : 0u;
-                rank += d5 < dist + ((k ^ 5u) > k ? 1u : 0u) ? 1u : 0u;
-                rank += d6 < dist + ((k ^ 6u) > k ? 1u : 0u) ? 1u : 0u;
-                rank += m < dist + ((k ^ 7u) > k ? 1u : 0u) ? 1u : 0u;
+                // [d < dist + c] as the sign bit of the 32-bit difference (all operands are below 2^31): no v_cmp -> vcc -> v_addc chain
+                rank = (d1 - (dist + ((k ^ 1u) > k ? 1u : 0u))) >> 31;
+                rank += (d2 - (dist + ((k ^ 2u) > k ? 1u : 0u))) >> 31;
+                rank += (d3 - (dist + ((k ^ 3u) > k ? 1u : 0u))) >> 31;
+                rank += (d4 - (dist + ((k ^ 4u) > k ? 1u : 0u))) >> 31;
+                rank += (d5 - (dist + ((k ^ 5u) > k ? 1u : 0u))) >> 31;
+                rank += (d6 - (dist + ((k ^ 6u) > k ? 1u : 0u))) >> 31;
+                rank += (m - (dist + ((k ^ 7u) > k ? 1u : 0u))) >> 31;
                 // exactly four hit children with equal distances among them: the reference's 5-comparator network orders them
                 // differently (trace_common.hip.h, sort4_network); nhit is uniform within the octet
                 if (nhit == 4u) {
@@ -442,7 +442,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
         const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
         const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
-        dist[k] = h ? __float_as_uint(tN) : ~(uint32_t)k; // non-hit: distinct sentinels -1..-8 (inline constants) above every distance, see the tie detection below
+        // non-hit: distinct sentinels 0x7FFFFFF8..0x7FFFFFFF - above every distance (tN >= 0 is at most +inf = 0x7F800000) and, like the distances,
+        // below 2^31, so that the ranking below can take the sign of a 32-bit difference; distinct for the tie detection
+        dist[k] = h ? __float_as_uint(tN) : (0x7FFFFFF8u + (uint32_t)k);
         mask |= h ? (1u << k) : 0u;
       }
       const int nhit = __popc(mask);
@@ -471,15 +473,17 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           // traverseClosestHit: visit order = ascending uint(tNear), equal distances -> higher child index first
           // (strict compares in bvh_traverser1.h:590-591 and stack_item.h:39-80; four hit children: see below); non-hit
           // children carry sentinels above every distance and sort behind every hit child
+          // (round 3) aFirst = [dist[a] < dist[b]] is the sign bit of the 32-bit difference (all values are below 2^31): two VALU
+          // instructions without the v_cmp -> vcc -> v_addc chain and its hazard slots (100 s_nop in the 770 instructions of this step)
 #pragma unroll
-          for (int k = 0; k < 8; k++) rank[k] = 0;
+          for (int k = 0; k < 8; k++) rank[k] = (uint32_t)(7 - k); // child k is the lower index of 7-k pairs: counts them as "b first" ...
 #pragma unroll
           for (int a = 0; a < 8; a++) {
 #pragma unroll
             for (int b = a + 1; b < 8; b++) {
-              const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u; // tie -> b (higher index) first
+              const uint32_t aFirst = (dist[a] - dist[b]) >> 31; // tie -> 0 -> b (higher index) first
               rank[b] += aFirst;
-              rank[a] += 1u - aFirst;
+              rank[a] -= aFirst; // ... and takes back the pairs a wins
             }
           }
           // exactly four hit children: the reference's 5-comparator network decides ties differently (trace_common.hip.h)

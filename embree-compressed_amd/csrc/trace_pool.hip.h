@@ -232,7 +232,7 @@ __global__ __launch_bounds__(POOL_BLOCK, 2) void trace_pool_kernel(LaunchParams 
           const float tN = fmaxf(tr.nearT(npx, npy, npz), tr.tnear);
           const float tF = fminf(tr.farT(fpx, fpy, fpz), travFar);
           const bool h = (tN <= tF) & (cref[k] != REF_EMPTY);
-          dist[k] = h ? __float_as_uint(tN) : ~(uint32_t)k; // distinct sentinels -1..-8 (tie detection below)
+          dist[k] = h ? __float_as_uint(tN) : (0x7FFFFFF8u + (uint32_t)k); // distinct sentinels above every distance and below 2^31 (trace_loop.hip.h)
           mask |= h ? (1u << k) : 0u;
         }
         const int nhit = __popc(mask);
@@ -253,14 +253,14 @@ __global__ __launch_bounds__(POOL_BLOCK, 2) void trace_pool_kernel(LaunchParams 
             for (int k = 0; k < 8; k++) rank[k] = (uint32_t)__popc(mask >> (k + 1));
           } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) rank[k] = 0;
+            for (int k = 0; k < 8; k++) rank[k] = (uint32_t)(7 - k);
 #pragma unroll
             for (int a = 0; a < 8; a++) {
 #pragma unroll
               for (int b = a + 1; b < 8; b++) {
-                const uint32_t aFirst = dist[a] < dist[b] ? 1u : 0u;
+                const uint32_t aFirst = (dist[a] - dist[b]) >> 31; // [dist[a] < dist[b]], sign of the difference (trace_loop.hip.h)
                 rank[b] += aFirst;
-                rank[a] += 1u - aFirst;
+                rank[a] -= aFirst;
               }
             }
           }
