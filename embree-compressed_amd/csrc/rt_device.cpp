@@ -131,13 +131,6 @@ Device::Device(const char* cfg)
 
 Device::~Device()
 {
-  for (CombSlot& c : combSlots) { // the call combiner's slots (rt_trace.cpp trace_call)
-    if (gpu >= 0 && (c.host || c.stream)) (void)hipSetDevice(gpu);
-    if (c.stream) (void)hipStreamDestroy(c.stream);
-    if (c.host) (void)hipHostFree(c.host);
-    c.host = c.dev = nullptr;
-    c.stream = nullptr;
-  }
   for (auto& shp : shards) {
     GpuShard& sh = *shp;
     hipSetDevice(sh.ordinal);

@@ -137,22 +137,14 @@ struct Device : RefCounted
     size_t stride;
     bool occluded;
     uint32_t instID;
-    std::atomic<uint32_t> done{0}; // set (release) by the leader that traced the call; the caller polls it
-    std::atomic<bool> taken{false}; // a leader has collected the call (written under combMutex, polled without it)
+    bool done = false;
     RTCError error = RTC_ERROR_NONE;
     std::string message;
   };
   std::mutex combMutex;
   std::condition_variable combCv;
   std::vector<SmallCall*> combPending;
-  // Up to COMB_SLOTS leaders at a time (round 3): each traces its batch in its own pinned, device-mapped slot on its own stream, so that the
-  // calls that arrive while one combined launch is on the GPU form the next launch at once instead of waiting for the first to return
-  static const int COMB_SLOTS = 3;
-  static const uint32_t COMB_SLOT_RAYS = 4096; // rays a slot holds (80 B each); larger combined batches take the general host path
-  struct CombSlot { void* host = nullptr; void* dev = nullptr; hipStream_t stream = nullptr; bool busy = false; };
-  CombSlot combSlots[COMB_SLOTS];
-  std::atomic<int> combLeaders{0}; // changed under combMutex, polled without it
-  std::atomic<uint32_t> combPendingCount{0};
+  bool combBusy = false;
   std::atomic<bool> combHold{false}; // test hook: rtcamdDebugHoldCombiner
   std::atomic<uint64_t> statLaunches{0};      // traversal kernel launches
   std::atomic<uint64_t> statCombinedCalls{0}; // calls that went through the combiner

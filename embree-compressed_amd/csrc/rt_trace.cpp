@@ -608,27 +608,7 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
 // (SURVEY.md section 8b "Threading"), so the calls that arrive while a launch is in flight are traced together by the
 // next leader: T calling threads then see ~T rays per launch instead of one.  Results are those of independent calls
 // (a stream is M independent single-ray calls); no timer, no extra thread, no CPU traversal.
-// A group of combined calls traced in a leader's own slot (pinned host memory the kernels read and write in place over PCIe, own stream):
-// no staging buffers shared with other callers, no device-wide lock, completion polled with hipStreamQuery.
-static void trace_in_slot(Device* dev, Device::CombSlot& slot, Scene* s, char* base, uint32_t total, uint32_t rec, bool occluded, uint32_t instID)
-{
-  if (s->modified) RT_THROW(RTC_ERROR_INVALID_OPERATION, "scene got not committed"); // scene.cpp:25,54
-  Device::GpuShard& sh = dev->primary();
-  sh.use();
-  launch_on(s, s->triAccel, 0, slot.dev, total, rec, occluded, instID, nullptr, nullptr, nullptr, nullptr, false, nullptr, slot.stream);
-  launch_on(s, s->subdivAccel, 0, slot.dev, total, rec, occluded, instID, nullptr, nullptr, nullptr, nullptr, false, nullptr, slot.stream);
-  unsigned spins = 0;
-  for (;;) {
-    const hipError_t e = hipStreamQuery(slot.stream);
-    if (e == hipSuccess) break;
-    if (e != hipErrorNotReady) HIP_CHECK(e);
-    (void)hipGetLastError();
-    if (++spins > 200000u) { HIP_CHECK(hipStreamSynchronize(slot.stream)); break; } // a very long batch: stop polling
-  }
-  sh.checkOverflow();
-}
-
-static void combine_process(Device* dev, std::vector<Device::SmallCall*>& batch, Device::CombSlot* slot)
+static void combine_process(Device* dev, std::vector<Device::SmallCall*>& batch)
 {
   // group by (scene, kind, instID); each group becomes one contiguous batch
   std::vector<char> done(batch.size(), 0);
@@ -647,20 +627,15 @@ static void combine_process(Device* dev, std::vector<Device::SmallCall*>& batch,
     }
     const uint32_t rec = a->occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
     try {
-      const bool inSlot = slot && slot->host && total <= Device::COMB_SLOT_RAYS;
-      std::vector<char> tmp(inSlot ? 0 : total * rec + 16);
-      char* base = inSlot ? (char*)slot->host : (char*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
+      std::vector<char> tmp(total * rec + 16);
+      char* base = (char*)(((uintptr_t)tmp.data() + 15) & ~(uintptr_t)15);
       size_t k = 0;
       for (Device::SmallCall* c : group)
         for (uint32_t r = 0; r < c->M; r++, k++) memcpy(base + k * rec, c->base + (size_t)r * c->stride, rec);
-      if (inSlot)
-        trace_in_slot(dev, *slot, a->scene, base, (uint32_t)total, rec, a->occluded, a->instID);
-      else {
-        RTCIntersectContext ctx;
-        memset(&ctx, 0, sizeof(ctx));
-        ctx.instID[0] = a->instID;
-        trace_batch(a->scene, base, (uint32_t)total, rec, a->occluded, &ctx, nullptr);
-      }
+      RTCIntersectContext ctx;
+      memset(&ctx, 0, sizeof(ctx));
+      ctx.instID[0] = a->instID;
+      trace_batch(a->scene, base, (uint32_t)total, rec, a->occluded, &ctx, nullptr);
       k = 0;
       for (Device::SmallCall* c : group)
         for (uint32_t r = 0; r < c->M; r++, k++) {
@@ -675,17 +650,6 @@ static void combine_process(Device* dev, std::vector<Device::SmallCall*>& batch,
       for (Device::SmallCall* c : group) { c->error = RTC_ERROR_UNKNOWN; c->message = e.what(); }
     }
   }
-}
-
-// one step of a caller's wait: the CPU's spin hint, now and then a yield
-static inline void call_relax(unsigned& spins)
-{
-#if defined(__x86_64__) || defined(__i386__)
-  __builtin_ia32_pause();
-#elif defined(__aarch64__)
-  asm volatile("yield");
-#endif
-  if ((++spins & 1023u) == 0u) std::this_thread::yield();
 }
 
 void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occluded, const RTCIntersectContext* ctx)
@@ -705,18 +669,10 @@ void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlud
   call.instID = ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID;
   std::unique_lock<std::mutex> lk(dev->combMutex);
   dev->combPending.push_back(&call);
-  dev->combPendingCount.fetch_add(1, std::memory_order_relaxed);
   dev->statCombinedCalls++; // counted once the call is pending (the held-leader test waits on this count)
-  unsigned spins = 0;
-  for (;;) { // lk is held at the top of every round
-    if (call.done.load(std::memory_order_acquire)) break;
-    const bool held = dev->combHold.load(std::memory_order_acquire);
-    if (!call.taken.load(std::memory_order_relaxed) && dev->combLeaders.load(std::memory_order_relaxed) < (held ? 1 : Device::COMB_SLOTS)) {
-      // become a leader for everything that is pending now (own call included): up to COMB_SLOTS leaders work at a time
-      dev->combLeaders++;
-      Device::CombSlot* slot = nullptr;
-      for (Device::CombSlot& c : dev->combSlots)
-        if (!c.busy) { slot = &c; c.busy = true; break; }
+  while (!call.done) {
+    if (!dev->combBusy) { // become the leader for everything that is pending now (own call included)
+      dev->combBusy = true;
       while (dev->combHold.load(std::memory_order_acquire)) { // test hook (rtcamdDebugHoldCombiner): the leader waits, the others queue up behind it
         lk.unlock();
         std::this_thread::yield();
@@ -724,38 +680,14 @@ void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlud
       }
       std::vector<Device::SmallCall*> batch;
       batch.swap(dev->combPending);
-      dev->combPendingCount.store(0, std::memory_order_relaxed);
-      for (Device::SmallCall* c : batch) c->taken.store(true, std::memory_order_relaxed);
       lk.unlock();
-      if (slot && !slot->host && dev->gpu >= 0) { // first use of this slot (only its leader touches it)
-        try {
-          dev->useDevice();
-          HIP_CHECK(hipHostMalloc(&slot->host, (size_t)Device::COMB_SLOT_RAYS * sizeof(RTCRayHit), hipHostMallocMapped));
-          HIP_CHECK(hipHostGetDevicePointer(&slot->dev, slot->host, 0));
-          HIP_CHECK(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking));
-        } catch (...) { // without a slot the batch takes the general host path
-          if (slot->host) (void)hipHostFree(slot->host);
-          slot->host = slot->dev = nullptr;
-        }
-      }
-      combine_process(dev, batch, slot);
+      combine_process(dev, batch);
       lk.lock();
-      for (Device::SmallCall* c : batch) c->done.store(1u, std::memory_order_release);
-      if (slot) slot->busy = false;
-      dev->combLeaders--;
+      for (Device::SmallCall* c : batch) c->done = true;
+      dev->combBusy = false;
       dev->combCv.notify_all();
-      continue;
-    }
-    // somebody else is tracing this call (or all leader slots are taken): poll without the lock, sleep only after a long wait
-    lk.unlock();
-    bool again = false;
-    for (unsigned k = 0; k < 20000u && !again; k++) {
-      if (call.done.load(std::memory_order_acquire)) again = true;
-      else if (!call.taken.load(std::memory_order_relaxed) && dev->combLeaders.load(std::memory_order_relaxed) < Device::COMB_SLOTS) again = true; // a leader slot is free: take it
-      else call_relax(spins);
-    }
-    lk.lock();
-    if (!again && !call.done.load(std::memory_order_acquire)) dev->combCv.wait_for(lk, std::chrono::microseconds(200));
+    } else
+      dev->combCv.wait(lk);
   }
   lk.unlock();
   if (call.error != RTC_ERROR_NONE) throw rtc_error(call.error, call.message);
