@@ -5,6 +5,8 @@
 #include <mutex>
 
 #include <algorithm>
+#include <cmath>
+#include <cstring>
 #include <unordered_map>
 
 namespace rtamd {
@@ -756,6 +758,27 @@ static void refine_and_emit(const Geometry* geom, unsigned geomID, unsigned L, L
     for (size_t k = 0; k < N; k++) {
       const D3& p = limit[g[k]];
       pg.x[k] = (float)p.x; pg.y[k] = (float)p.y; pg.z[k] = (float)p.z;
+    }
+    // development aid (encoder sensitivity): RTAMD_DEBUG_GRID_JITTER=<seed> moves every grid coordinate by -1, 0 or +1 ulp,
+    // the same way for equal positions (a hash of the position's bits), i.e. by less than the difference between two correct fp32 evaluations
+    // of the limit surface - what the reference's float B-spline evaluation and this double-precision refinement differ by
+    static const char* jit = getenv("RTAMD_DEBUG_GRID_JITTER");
+    if (jit && atoi(jit) != 0) {
+      const uint32_t seed = (uint32_t)atoi(jit);
+      for (size_t k = 0; k < N; k++) {
+        uint32_t b[3];
+        memcpy(&b[0], &pg.x[k], 4); memcpy(&b[1], &pg.y[k], 4); memcpy(&b[2], &pg.z[k], 4);
+        uint32_t h = seed * 0x9E3779B9u ^ b[0];
+        h = (h ^ (h >> 15)) * 0x2C1B3C6Du ^ b[1];
+        h = (h ^ (h >> 12)) * 0x297A2D39u ^ b[2];
+        h ^= h >> 15;
+        float* c[3] = {&pg.x[k], &pg.y[k], &pg.z[k]};
+        for (int a = 0; a < 3; a++) {
+          const uint32_t r = (h >> (8 * a)) % 3u;
+          if (r == 1u) *c[a] = nextafterf(*c[a], INFINITY);
+          else if (r == 2u) *c[a] = nextafterf(*c[a], -INFINITY);
+        }
+      }
     }
     if (displ) {
       pg.bx = pg.x; pg.by = pg.y; pg.bz = pg.z;

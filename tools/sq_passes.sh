@@ -14,11 +14,14 @@ if [ "$SQP_SETS" = mem ]; then
         "TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_STALL_MULTI_MISS_sum"
         "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum"
         "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum TCC_BUSY_sum"
-        "TA_TOTAL_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+        "TA_TOTAL_WAVEFRONTS_sum" "TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TA_DATA_STALLED_BY_TC_CYCLES_sum"
         "TA_BUSY_avr")
-  # round 2 had the derived metric TA_BUSY_avr (an average over the TA instances) in ONE pass with three raw TA_*_sum counters: rocprofv3 aborted
-  # with signal 6 in that pass (profiles/r02_cbvh_leaf_sq_stalls.txt).  The derived metric now has a pass of its own; the names offered by the
-  # box are recorded first (rocprofv3 --list-avail), and a pass that fails is reported with the end of its log and the sweep goes on.
+  # round 2 had TA_BUSY_avr in ONE pass with three TA_*_sum counters and rocprofv3 aborted with signal 6 (profiles/r02_cbvh_leaf_sq_stalls.txt).
+  # Round 3 located it: with the derived metric in a pass of its own (it works: 88 781) the THREE _sum counters together still abort, and the
+  # kept log says why - "rocprofiler_create_counter_config ... error code 38: Request exceeds the capabilities of the hardware to collect", a fatal
+  # check of the profiler tool at the first dispatch (inside rtcCommitScene's upload): every TA_*_sum sums one hardware counter per TA instance and
+  # the TA block has too few counter slots for three of them.  One TA counter per pass.  The names offered by the box are recorded first
+  # (rocprofv3 --list-avail), and a pass that fails is reported with the end of its log and the sweep goes on.
   (rocprofv3 --list-avail 2>/dev/null | grep -oE "TA_(BUSY|TOTAL_WAVEFRONTS|ADDR_STALLED_BY_TC_CYCLES|DATA_STALLED_BY_TC_CYCLES)[A-Za-z_]*" | sort -u | tr "\n" " "; echo) > $O/ta_counters_available.txt
   echo "# TA counters offered by rocprofv3 --list-avail on this box: $(cat $O/ta_counters_available.txt)" >> $O/summary.txt
 else
@@ -36,7 +39,8 @@ for set in "${SETS[@]}"; do
     python3 $R/tools/sq_summary.py $O/p$i >> $O/summary.txt
   else
     echo "pass failed (rc $?); end of its log (kept whole as log_$i.txt next to this file):" >> $O/summary.txt
-    tail -n 15 $O/log_$i.txt | cut -c1-300 >> $O/summary.txt
+    grep -B1 -A3 "failed with error code" $O/log_$i.txt | cut -c1-300 >> $O/summary.txt
+    tail -n 4 $O/log_$i.txt | cut -c1-300 >> $O/summary.txt
   fi
   rm -rf $O/p$i
 done
