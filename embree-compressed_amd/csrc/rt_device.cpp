@@ -4,6 +4,7 @@
 #include <pthread.h>
 
 #include "rt_objects.h"
+#include "rt_trace.h"
 
 namespace rtamd {
 
@@ -65,6 +66,7 @@ void Device::parse(const std::string& cfg)
       gpu = gpuList[0];
     }
     else if (key == "threads") numThreads = atoi(val.c_str());
+    else if (key == "service") tuneService = (uint32_t)std::max(0, atoi(val.c_str())); // persistent consumer for calls of up to 64 rays (also env RTAMD_SERVICE)
     else if (key == "host_threads") tuneHostThreads = (uint32_t)std::max(0, atoi(val.c_str())); // staging threads of pipelined host batches (also env RTAMD_HOST_THREADS)
     else if (key == "benchmark") benchmark = atoi(val.c_str());
     else if (key == "keep_grids") keepGrids = atoi(val.c_str());
@@ -76,6 +78,7 @@ Device::Device(const char* cfg)
 {
   if (const char* env = getenv("RTAMD_GPU")) gpu = atoi(env);
   if (const char* env = getenv("RTAMD_CHUNK")) { tuneChunk = (uint32_t)std::max(1, atoi(env)); tuneChunkFixed = true; }
+  if (const char* env = getenv("RTAMD_SERVICE")) tuneService = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_LEAF_BATCH")) tuneLeafBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_REFILL_BATCH")) tuneRefillBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_LEAF")) tuneOctLeaf = (uint32_t)std::max(0, atoi(env));
@@ -131,6 +134,7 @@ Device::Device(const char* cfg)
 
 Device::~Device()
 {
+  service_destroy(this);
   for (auto& shp : shards) {
     GpuShard& sh = *shp;
     hipSetDevice(sh.ordinal);

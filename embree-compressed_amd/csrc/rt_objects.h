@@ -141,12 +141,18 @@ struct Device : RefCounted
     RTCError error = RTC_ERROR_NONE;
     std::string message;
   };
+  // Persistent consumer for calls of up to 64 rays (trace_service.hip.h, rt_trace.cpp service_trace): env RTAMD_SERVICE / config key service=1
+  struct Service;
+  Service* service = nullptr;
+  std::mutex serviceMutex; // creation / restart of the service kernel
+  uint32_t tuneService = 0;
   std::mutex combMutex;
   std::condition_variable combCv;
   std::vector<SmallCall*> combPending;
   bool combBusy = false;
   std::atomic<bool> combHold{false}; // test hook: rtcamdDebugHoldCombiner
   std::atomic<uint64_t> statLaunches{0};      // traversal kernel launches
+  std::atomic<uint64_t> statServiceCalls{0};  // calls answered by the persistent service kernel
   std::atomic<uint64_t> statCombinedCalls{0}; // calls that went through the combiner
   std::atomic<uint64_t> statCombinedBatches{0}; // batches the combiner formed out of them
   uint32_t tuneRefillBatch = 8; // env RTAMD_REFILL_BATCH

@@ -3,6 +3,7 @@
 
 #include "bvh8_builder.h"
 #include "rt_objects.h"
+#include "rt_trace.h"
 #include "subdiv_build.h"
 
 namespace rtamd {
@@ -195,6 +196,7 @@ Scene::Scene(Device* d) : device(d) { device->retain(); }
 
 Scene::~Scene()
 {
+  service_quiesce(device); // freeing device memory synchronises the device: do not wait for the resident service kernel's idle exit
   triAccel.freeDevice();
   subdivAccel.freeDevice();
   if (device->gpu >= 0) hipSetDevice(device->gpu);
@@ -310,6 +312,7 @@ static void build_triangle_accel(Scene* s)
 void Scene::commit()
 {
   std::lock_guard<std::mutex> g(buildMutex);
+  service_quiesce(device); // the upload allocates device memory (see Scene::~Scene)
   for (Geometry* geo : geometries) {
     if (!geo || !geo->enabled) continue;
     switch (geo->type) {

@@ -602,6 +602,221 @@ void trace_batch(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlu
   }
 }
 
+// ---- persistent consumer for small calls (row f2) -------------------------------------------------------------
+// See trace_service.hip.h.  One resident kernel per RTCDevice, for the accel kind of the first scene that makes a small call; a caller owns
+// one slot of the ring for the duration of its call (threads are dealt slots round-robin; two threads that share a slot take turns).
+struct Device::Service
+{
+  static const uint32_t SLOTS = 64;          // wavefronts of the service kernel = calls in flight
+  static const uint32_t SPILL_DEPTH = 512;   // HBM stack overflow entries per lane the service can offer (scenes that need more keep the combiner)
+  uint32_t kind = 0, levels = 0;
+  hipStream_t stream = nullptr;
+  ServiceSlot* slotsHost = nullptr;
+  ServiceSlot* slotsDev = nullptr;
+  uint32_t* stopHost = nullptr;
+  uint32_t* stopDev = nullptr;
+  uint32_t* activityDev = nullptr;
+  void* spillDev = nullptr;
+  LaunchParams base;
+  std::atomic<uint32_t> slotLock[SLOTS];
+  uint32_t slotSeq[SLOTS];
+  std::atomic<uint32_t> nextSlot{0};
+  std::atomic<uint64_t> lastSubmitNs{0};
+  std::atomic<uint64_t> starts{0};
+  bool failed = false;
+};
+
+// every live service, so that a process that exits without releasing its RTCDevice still stops the resident kernels BEFORE the runtime tears
+// down the host-mapped ring they poll (a kernel reading freed host memory faults the GPU)
+static std::mutex g_serviceRegistryMutex;
+static std::vector<Device::Service*> g_serviceRegistry;
+static void service_stop_all_at_exit()
+{
+  std::lock_guard<std::mutex> g(g_serviceRegistryMutex);
+  for (Device::Service* sv : g_serviceRegistry) {
+    if (sv->stopHost) __atomic_store_n(sv->stopHost, 1u, __ATOMIC_RELEASE);
+    if (sv->stream) (void)hipStreamSynchronize(sv->stream);
+  }
+  g_serviceRegistry.clear();
+}
+static void service_register(Device::Service* sv)
+{
+  std::lock_guard<std::mutex> g(g_serviceRegistryMutex);
+  static bool hooked = false;
+  if (!hooked) { atexit(service_stop_all_at_exit); hooked = true; }
+  g_serviceRegistry.push_back(sv);
+}
+static void service_unregister(Device::Service* sv)
+{
+  std::lock_guard<std::mutex> g(g_serviceRegistryMutex);
+  g_serviceRegistry.erase(std::remove(g_serviceRegistry.begin(), g_serviceRegistry.end(), sv), g_serviceRegistry.end());
+}
+
+static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void service_destroy(Device* dev)
+{
+  Device::Service* sv = dev->service;
+  if (!sv) return;
+  dev->service = nullptr;
+  service_unregister(sv);
+  if (dev->gpu >= 0) (void)hipSetDevice(dev->gpu);
+  if (sv->stopHost) __atomic_store_n(sv->stopHost, 1u, __ATOMIC_RELEASE);
+  if (sv->stream) { (void)hipStreamSynchronize(sv->stream); (void)hipStreamDestroy(sv->stream); }
+  if (sv->slotsHost) (void)hipHostFree(sv->slotsHost);
+  if (sv->stopHost) (void)hipHostFree(sv->stopHost);
+  if (sv->activityDev) (void)hipFree(sv->activityDev);
+  if (sv->spillDev) (void)hipFree(sv->spillDev);
+  delete sv;
+}
+
+// Stop the service kernel and wait for it (it restarts on demand): before the library allocates or frees device memory, which synchronises
+// the whole device and would otherwise wait for the resident kernel's idle exit.  Jobs in flight are finished first; a job that arrives in
+// between is served after the restart its caller triggers.
+void service_quiesce(Device* dev)
+{
+  if (!dev->service) return;
+  std::lock_guard<std::mutex> g(dev->serviceMutex);
+  Device::Service* sv = dev->service;
+  if (!sv || sv->failed || !sv->stream) return;
+  if (dev->gpu >= 0) (void)hipSetDevice(dev->gpu);
+  __atomic_store_n(sv->stopHost, 1u, __ATOMIC_RELEASE);
+  (void)hipStreamSynchronize(sv->stream);
+  __atomic_store_n(sv->stopHost, 0u, __ATOMIC_RELEASE);
+}
+
+// (re)start the service kernel if it is not running; serviceMutex held
+static void service_start_locked(Device* dev, Device::Service* sv)
+{
+  const hipError_t q = hipStreamQuery(sv->stream);
+  if (q == hipErrorNotReady) { (void)hipGetLastError(); return; } // running
+  if (q != hipSuccess) HIP_CHECK(q);
+  ServiceParams sp;
+  sp.base = sv->base;
+  sp.slots = sv->slotsDev;
+  sp.numSlots = Device::Service::SLOTS;
+  sp.idlePolls = 16384u; // ~30 ms without a single job: the kernel leaves the GPU to itself
+  sp.stop = sv->stopDev;
+  sp.activity = sv->activityDev;
+  HIP_CHECK(launch_service(sp, sv->stream));
+  sv->starts++;
+}
+
+// Trace a call of up to 64 rays through the service.  false: not applicable (the caller falls back to the combiner).
+static bool service_trace(Scene* s, char* rays, uint32_t M, size_t byteStride, bool occluded, uint32_t instID)
+{
+  Device* dev = s->device;
+  if (!dev->tuneService || dev->gpu < 0 || dev->shards.size() != 1 || M > (uint32_t)SERVICE_SLOT_RAYS) return false;
+  const bool tri = s->triAccel.kind != ACCEL_NONE && s->triAccel.root != REF_EMPTY, sub = s->subdivAccel.kind != ACCEL_NONE && s->subdivAccel.root != REF_EMPTY;
+  if (tri == sub) return false; // two accels (AccelN) or none: the general path
+  const Accel& A = tri ? s->triAccel : s->subdivAccel;
+  const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
+  const uint32_t need = worst > (uint32_t)TRACE_LDS_STACK ? worst - TRACE_LDS_STACK : 0u;
+  if (need > Device::Service::SPILL_DEPTH) return false;
+  Device::GpuShard& sh = dev->primary();
+  Device::Service* sv = dev->service;
+  if (!sv) {
+    std::lock_guard<std::mutex> g(dev->serviceMutex);
+    if (!dev->service) {
+      sh.use();
+      std::unique_ptr<Device::Service> n(new Device::Service);
+      n->kind = A.kind;
+      n->levels = s->compressionLevel;
+      for (uint32_t i = 0; i < Device::Service::SLOTS; i++) { n->slotLock[i].store(0u); n->slotSeq[i] = 0u; }
+      LaunchParams& p = n->base;
+      memset(&p, 0, sizeof(p));
+      p.accel = A.desc(0);
+      p.cbvhLevels = s->compressionLevel;
+      p.numCUs = (uint32_t)sh.numCUs;
+      p.rayChunk = (uint32_t)SERVICE_SLOT_RAYS;
+      p.leafBatch = dev->tuneLeafBatch;
+      p.refillBatch = dev->tuneRefillBatch;
+      p.octMax = dev->tuneOctMax;
+      p.octSteps = dev->tuneOctSteps;
+      p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : (A.kind == ACCEL_GRIDSOA ? 24u : 16u);
+      p.overflow = sh.overflowDev;
+      p.spillDepth = Device::Service::SPILL_DEPTH;
+      p.gridBlocks = Device::Service::SLOTS / (TRACE_BLOCK / 64);
+      try {
+        HIP_CHECK(hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipHostMalloc((void**)&n->slotsHost, sizeof(ServiceSlot) * Device::Service::SLOTS, hipHostMallocMapped));
+        memset(n->slotsHost, 0, sizeof(ServiceSlot) * Device::Service::SLOTS);
+        HIP_CHECK(hipHostGetDevicePointer((void**)&n->slotsDev, n->slotsHost, 0));
+        HIP_CHECK(hipHostMalloc((void**)&n->stopHost, 128, hipHostMallocMapped));
+        memset(n->stopHost, 0, 128);
+        HIP_CHECK(hipHostGetDevicePointer((void**)&n->stopDev, n->stopHost, 0));
+        HIP_CHECK(hipMalloc((void**)&n->activityDev, 128));
+        HIP_CHECK(hipMemset(n->activityDev, 0, 128));
+        HIP_CHECK(hipMalloc(&n->spillDev, (size_t)Device::Service::SLOTS * 64u * Device::Service::SPILL_DEPTH * 8u + 16u));
+        p.spill = n->spillDev;
+        service_register(n.get());
+        service_start_locked(dev, n.get());
+      } catch (...) { // no service kernel for this accel kind / level, or out of memory: the combiner serves the calls
+        n->failed = true;
+        (void)hipGetLastError();
+      }
+      dev->service = n.release();
+    }
+    sv = dev->service;
+  }
+  if (sv->failed || sv->kind != A.kind || (sv->levels != s->compressionLevel && A.kind != ACCEL_TRI_PLUECKER && A.kind != ACCEL_TRI_MOELLER && A.kind != ACCEL_GRIDSOA)) return false;
+
+  // a slot: threads are dealt slots round-robin once; a shared slot is taken in turns
+  static thread_local uint32_t mySlot = 0xFFFFFFFFu;
+  static thread_local const Device::Service* mySlotOf = nullptr;
+  if (mySlotOf != sv) { mySlot = sv->nextSlot.fetch_add(1u) % Device::Service::SLOTS; mySlotOf = sv; }
+  unsigned spins = 0;
+  for (;;) {
+    uint32_t expect = 0u;
+    if (sv->slotLock[mySlot].compare_exchange_weak(expect, 1u, std::memory_order_acquire)) break;
+    if ((++spins & 255u) == 0u) std::this_thread::yield();
+  }
+  struct Unlock { std::atomic<uint32_t>& l; ~Unlock() { l.store(0u, std::memory_order_release); } } unlock{sv->slotLock[mySlot]};
+
+  const uint64_t t0 = now_ns();
+  if (t0 - sv->lastSubmitNs.load(std::memory_order_relaxed) > 10000000ull) { // quiet for 10 ms: the kernel may have left, look before the job goes in
+    std::lock_guard<std::mutex> g(dev->serviceMutex);
+    sh.use();
+    service_start_locked(dev, sv);
+  }
+  sv->lastSubmitNs.store(t0, std::memory_order_relaxed);
+  ServiceSlot& slot = sv->slotsHost[mySlot];
+  const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
+  for (uint32_t i = 0; i < M; i++) memcpy(slot.rays + (size_t)i * rec, rays + (size_t)i * byteStride, rec);
+  slot.count = M;
+  slot.occluded = occluded ? 1u : 0u;
+  slot.instID = instID;
+  slot.spillDepth = need;
+  slot.accel = A.desc(0);
+  const uint32_t seq = ++sv->slotSeq[mySlot];
+  __atomic_store_n(&slot.seq, seq, __ATOMIC_RELEASE);
+  spins = 0;
+  uint64_t lastCheck = t0;
+  while (__atomic_load_n(&slot.done, __ATOMIC_ACQUIRE) != seq) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+    if ((++spins & 4095u) == 0u) {
+      const uint64_t t = now_ns();
+      if (t - lastCheck > 2000000ull) { // 2 ms without an answer: has the kernel left (idle exit raced with this job)?  restart it
+        std::lock_guard<std::mutex> g(dev->serviceMutex);
+        sh.use();
+        service_start_locked(dev, sv);
+        lastCheck = t;
+      }
+      if (t - t0 > 5000000000ull) RT_THROW(RTC_ERROR_UNKNOWN, "the small-call service kernel does not answer");
+    }
+  }
+  for (uint32_t i = 0; i < M; i++) {
+    char* dst = rays + (size_t)i * byteStride;
+    const char* src = slot.rays + (size_t)i * rec;
+    memcpy(dst + 32, src + 32, 4);
+    if (!occluded) memcpy(dst + 48, src + 48, 32);
+  }
+  dev->statServiceCalls++;
+  return true;
+}
+
 // ---- call combiner (row f2) -----------------------------------------------------------------------------------------
 // The reference answers rtcIntersect1 in ~1 us on the calling core; here a call costs a staging copy, a kernel launch
 // and a synchronisation (~60 us) whatever its size.  Harness threads of an embree application call concurrently
@@ -660,6 +875,7 @@ void trace_call(Scene* s, void* rays, uint32_t M, size_t byteStride, bool occlud
     trace_batch(s, rays, M, byteStride, occluded, ctx, nullptr); // large, device-resident, or about to raise its own error
     return;
   }
+  if (service_trace(s, (char*)rays, M, byteStride, occluded, ctx ? ctx->instID[0] : RTC_INVALID_GEOMETRY_ID)) return;
   Device::SmallCall call;
   call.scene = s;
   call.base = (char*)rays;

@@ -94,6 +94,7 @@ API ssize_t rtcGetDeviceProperty(RTCDevice h, enum RTCDeviceProperty prop)
   case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES: return (ssize_t)D(h)->statLaunches.load();
   case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS: return (ssize_t)D(h)->statCombinedCalls.load();
   case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES: return (ssize_t)D(h)->statCombinedBatches.load();
+  case (RTCDeviceProperty)RTCAMD_DEVICE_PROPERTY_SERVICE_CALLS: return (ssize_t)D(h)->statServiceCalls.load();
   default: RT_THROW(RTC_ERROR_INVALID_ARGUMENT, "unknown readable property");
   }
   CATCH_END(D(h))

@@ -51,6 +51,35 @@ struct LaunchParams
                            // whose depth the builder reported correctly: the overflow area is sized for the worst case)
 };
 
+// ---- persistent consumer for small calls (trace_service.hip.h, rt_service.cpp) ---------------------------------------------
+static const int SERVICE_SLOT_RAYS = 64; // one wavefront, one ray per lane
+struct alignas(128) ServiceSlot // host-mapped pinned memory, one per wavefront of the service kernel
+{
+  uint32_t seq;        // host -> device: number of the slot's current job, written LAST (release)
+  uint32_t count;      // rays of the job (<= SERVICE_SLOT_RAYS)
+  uint32_t occluded;   // 0: RTCRayHit records (80 B), 1: RTCRay records (48 B)
+  uint32_t instID;
+  uint32_t spillDepth; // HBM stack overflow entries this scene's depth needs (<= what the service allocated)
+  uint32_t pad0[3];
+  AccelDesc accel;     // the committed scene's device arrays (replica of the service's GPU)
+  uint32_t pad1[32 - 8 - sizeof(AccelDesc) / 4];
+  uint32_t done;       // device -> host: sequence number of the last finished job (own 128-byte line)
+  uint32_t pad2[31];
+  char rays[SERVICE_SLOT_RAYS * 80];
+};
+struct ServiceParams
+{
+  LaunchParams base;   // tuning knobs, overflow area, overflow flag; rays / count / accel come from the slot per job
+  ServiceSlot* slots;  // device address of the ring
+  uint32_t numSlots;   // = wavefronts of the service kernel
+  uint32_t idlePolls;  // polls without ANY served job after which the service ends by itself
+  uint32_t* stop;      // host-mapped: non-zero = leave now
+  uint32_t* activity;  // device word: jobs served by any wavefront
+};
+// start the service kernel for base.accel.kind (and base.cbvhLevels); hipErrorInvalidValue: no service kernel for this accel kind / level
+hipError_t launch_service_tri(const ServiceParams& s, hipStream_t stream);    // trace_tri.hip
+hipError_t launch_service_subdiv(const ServiceParams& s, hipStream_t stream); // trace_subdiv.hip
+
 static const int TRACE_QUEUES = 64;       // work queues per launch (must equal the wavefront width: one lane scans one head)
 static const int TRACE_QUEUE_STRIDE = 32; // u32 words between two work-queue heads (128 B: one L2 line each)
 #ifndef TRACE_BLOCK_THREADS
@@ -78,6 +107,19 @@ uint32_t trace_grid_blocks(uint32_t count, int numCUs, uint32_t rayChunk);
 hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream);    // trace_tri.hip
 hipError_t launch_cull(const LaunchParams& p, hipStream_t stream);         // trace_tri.hip (trace_cull.hip.h): root cull pre-pass
 hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream); // trace_subdiv.hip
+inline hipError_t launch_service(const ServiceParams& s, hipStream_t stream)
+{
+  switch (s.base.accel.kind) {
+  case ACCEL_TRI_PLUECKER:
+  case ACCEL_TRI_MOELLER: return launch_service_tri(s, stream);
+  case ACCEL_CBVH_BOX:
+  case ACCEL_CBVH_LEAF:
+  case ACCEL_CBVH_GRID:
+  case ACCEL_CBVH_FULL:
+  case ACCEL_GRIDSOA: return launch_service_subdiv(s, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
 inline hipError_t launch_trace(const LaunchParams& p, hipStream_t stream)
 {
   switch (p.accel.kind) {

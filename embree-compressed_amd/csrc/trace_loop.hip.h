@@ -79,7 +79,8 @@ template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
-template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC>
+// DIRECT (service kernel, trace_service.hip.h): the rays [0, P.count) belong to THIS wavefront - no work queues, nothing to grab
+template <typename Leaf, bool ROBUST, bool OCCLUDED, bool COUNT, bool VEC, bool DIRECT = false>
 __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsStack)[TRACE_BLOCK], float (*octX)[OCT_WORDS])
 {
   const uint32_t tid = threadIdx.x;
@@ -109,7 +110,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     return min(lo + perQ, P.count) - lo;
   };
   uint32_t qCur = (blockIdx.x * (TRACE_BLOCK / 64) + (tid >> 6)) & (uint32_t)(TRACE_QUEUES - 1); // wave-uniform
-  uint32_t poolNext = 0, poolEnd = 0; // wave-uniform: rays [poolNext, poolEnd) belong to this wave
+  uint32_t poolNext = 0, poolEnd = DIRECT ? P.count : 0u; // wave-uniform: rays [poolNext, poolEnd) belong to this wave
   // Staggered exhaustion: a quarter of the waves treats a queue as closed once 85 % of it are handed out, another quarter
   // at 92 %, the rest drains it.  The waves then enter their drain (few deep rays, few active lanes) at different times
   // instead of all at once; the SIMD slots of the early leavers are free for the other batches in flight.  Measured on
@@ -192,7 +193,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     // refilling a handful of lanes costs as many instructions as refilling all 64: wait until refillBatch lanes are
     // idle (or until nothing else can run)
     if (idleMask != 0ull && !exhausted && (__popcll(idleMask) >= (int)P.refillBatch || idleMask == ~0ull)) {
-      if (poolNext == poolEnd) { // take a new chunk (one lane does the atomic, the result is wave-uniform)
+      if (DIRECT && poolNext == poolEnd) exhausted = true;
+      else if (poolNext == poolEnd) { // take a new chunk (one lane does the atomic, the result is wave-uniform)
         for (;;) {
           const uint32_t qLo = qCur * perQ; // first entry of the queue (ray index, or position in the survivor lists)
           const uint32_t qLen = queue_len(qCur);

@@ -14,6 +14,7 @@
 // compiler; this path is "parity unpinned").
 #include "trace_loop.hip.h"
 #include "trace_pool.hip.h"
+#include "trace_service.hip.h"
 
 namespace rtamd {
 namespace dev {
@@ -1041,6 +1042,34 @@ template <int MODE> hipError_t launch_cbvh(const LaunchParams& p, hipStream_t st
 }
 
 } // namespace dev
+
+// service kernels (trace_service.hip.h): grid cells, and the fork's four modes in the quad form at the compression levels the tutorials use
+// (C = 2: the framework's default, 3: bomberman.ecs, 4: displacement_geometry); other levels keep the call combiner
+template <int MODE> static hipError_t launch_service_cbvh(const ServiceParams& s, hipStream_t stream)
+{
+  switch (s.base.cbvhLevels) {
+#ifndef TRACE_DEV_METRIC_ONLY
+  case 2: return dev::launch_service_kernel<dev::CbvhLeaf<MODE, 2, true>, true>(s, stream);
+  case 4: return dev::launch_service_kernel<dev::CbvhLeaf<MODE, 4, true>, true>(s, stream);
+#endif
+  case 3: return dev::launch_service_kernel<dev::CbvhLeaf<MODE, 3, true>, true>(s, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_service_subdiv(const ServiceParams& s, hipStream_t stream)
+{
+  switch (s.base.accel.kind) {
+#ifndef TRACE_DEV_METRIC_ONLY
+  case ACCEL_GRIDSOA: return dev::launch_service_kernel<dev::GridCellLeaf, true>(s, stream);
+  case ACCEL_CBVH_BOX: return launch_service_cbvh<dev::MODE_BOX>(s, stream);
+  case ACCEL_CBVH_GRID: return launch_service_cbvh<dev::MODE_GRID>(s, stream);
+  case ACCEL_CBVH_FULL: return launch_service_cbvh<dev::MODE_FULL>(s, stream);
+#endif
+  case ACCEL_CBVH_LEAF: return launch_service_cbvh<dev::MODE_LEAF>(s, stream);
+  default: return hipErrorInvalidValue;
+  }
+}
 
 hipError_t launch_trace_subdiv(const LaunchParams& p, hipStream_t stream)
 {

@@ -5,6 +5,7 @@
 //   epilog / tie rules    kernels/geometry/intersector_epilog.h:226-307 (closest), :388-450 (any hit)
 #include "trace_loop.hip.h"
 #include "trace_pool.hip.h"
+#include "trace_service.hip.h"
 #include "trace_cull.hip.h"
 
 namespace rtamd {
@@ -165,6 +166,16 @@ hipError_t launch_cull(const LaunchParams& p, hipStream_t stream)
   const bool robust = p.accel.kind != ACCEL_TRI_MOELLER;
   if (robust) return p.occluded ? dev::launch_cull_vec<true, true>(p, stream) : dev::launch_cull_vec<true, false>(p, stream);
   return p.occluded ? dev::launch_cull_vec<false, true>(p, stream) : dev::launch_cull_vec<false, false>(p, stream);
+}
+
+hipError_t launch_service_tri(const ServiceParams& s, hipStream_t stream)
+{
+#ifdef TRACE_DEV_METRIC_ONLY
+  return hipErrorInvalidValue;
+#else
+  if (s.base.accel.kind == ACCEL_TRI_PLUECKER) return dev::launch_service_kernel<dev::TriLeaf<true>, true>(s, stream);
+  return dev::launch_service_kernel<dev::TriLeaf<false>, false>(s, stream);
+#endif
 }
 
 hipError_t launch_trace_tri(const LaunchParams& p, hipStream_t stream)

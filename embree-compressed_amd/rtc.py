@@ -90,6 +90,7 @@ class RTCInterpolateNArguments(C.Structure):
 RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES = 240
 RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS = 241
 RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES = 242
+RTCAMD_DEVICE_PROPERTY_SERVICE_CALLS = 243
 
 
 class RTCAMDTraceCounters(C.Structure):

@@ -40,7 +40,8 @@ enum RTCAMDDeviceProperty
 {
   RTCAMD_DEVICE_PROPERTY_TRACE_LAUNCHES = 240,     /* traversal kernel launches so far */
   RTCAMD_DEVICE_PROPERTY_COMBINED_CALLS = 241,     /* API calls that went through the combiner */
-  RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES = 242 /* batches formed out of them */
+  RTCAMD_DEVICE_PROPERTY_COMBINED_BATCHES = 242, /* batches formed out of them */
+  RTCAMD_DEVICE_PROPERTY_SERVICE_CALLS = 243     /* API calls answered by the persistent small-call kernel (config key service=1) */
 };
 
 /* Layout facts of a committed scene's device acceleration structure; sizes in bytes.
