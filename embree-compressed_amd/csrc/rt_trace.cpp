@@ -789,6 +789,7 @@ static bool service_trace(Scene* s, char* rays, uint32_t M, size_t byteStride, b
   slot.spillDepth = need;
   slot.accel = A.desc(0);
   const uint32_t seq = ++sv->slotSeq[mySlot];
+  __atomic_store_n(&slot.seq2, seq, __ATOMIC_RELEASE);
   __atomic_store_n(&slot.seq, seq, __ATOMIC_RELEASE);
   spins = 0;
   uint64_t lastCheck = t0;
@@ -796,7 +797,8 @@ static bool service_trace(Scene* s, char* rays, uint32_t M, size_t byteStride, b
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
 #endif
-    if ((++spins & 4095u) == 0u) {
+    if ((++spins & 127u) == 0u) std::this_thread::yield(); // more callers than cores: let the others put their jobs in
+    if ((spins & 4095u) == 0u) {
       const uint64_t t = now_ns();
       if (t - lastCheck > 2000000ull) { // 2 ms without an answer: has the kernel left (idle exit raced with this job)?  restart it
         std::lock_guard<std::mutex> g(dev->serviceMutex);

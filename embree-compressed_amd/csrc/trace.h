@@ -1,6 +1,7 @@
 // Launch interface between the host object model and the HIP traversal kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include "accel.h"
 
@@ -55,18 +56,20 @@ struct LaunchParams
 static const int SERVICE_SLOT_RAYS = 64; // one wavefront, one ray per lane
 struct alignas(128) ServiceSlot // host-mapped pinned memory, one per wavefront of the service kernel
 {
-  uint32_t seq;        // host -> device: number of the slot's current job, written LAST (release)
+  uint32_t seq;        // host -> device: number of the slot's current job, written LAST (release), after seq2
   uint32_t count;      // rays of the job (<= SERVICE_SLOT_RAYS)
   uint32_t occluded;   // 0: RTCRayHit records (80 B), 1: RTCRay records (48 B)
   uint32_t instID;
   uint32_t spillDepth; // HBM stack overflow entries this scene's depth needs (<= what the service allocated)
   uint32_t pad0[3];
   AccelDesc accel;     // the committed scene's device arrays (replica of the service's GPU)
-  uint32_t pad1[32 - 8 - sizeof(AccelDesc) / 4];
+  uint32_t pad1[32 - 8 - sizeof(AccelDesc) / 4 - 1];
+  uint32_t seq2;       // copy of seq in the header's second 64-byte half, written BEFORE seq (trace_service.hip.h)
   uint32_t done;       // device -> host: sequence number of the last finished job (own 128-byte line)
   uint32_t pad2[31];
   char rays[SERVICE_SLOT_RAYS * 80];
 };
+static_assert(sizeof(ServiceSlot) == 256 + SERVICE_SLOT_RAYS * 80 && offsetof(ServiceSlot, done) == 128 && offsetof(ServiceSlot, seq2) == 124 && offsetof(ServiceSlot, rays) == 256, "ServiceSlot layout");
 struct ServiceParams
 {
   LaunchParams base;   // tuning knobs, overflow area, overflow flag; rays / count / accel come from the slot per job

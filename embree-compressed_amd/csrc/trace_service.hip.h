@@ -31,16 +31,27 @@ __global__ __launch_bounds__(TRACE_BLOCK, 2) void service_kernel(ServiceParams S
   uint32_t last = __builtin_amdgcn_readfirstlane(ld_sys(&slot->done));
   uint32_t idle = 0, seen = 0, quiet = 0;
   for (;;) {
-    const uint32_t seq = __builtin_amdgcn_readfirstlane(ld_sys(&slot->seq));
-    if (seq != last) {
+    // ONE access per poll: lane l reads word l of the slot's 128-byte header line (seq, count, flags, the accel's arrays) - a read of host
+    // memory is a PCIe round trip (~2 us), and the first version spent five of them on the header of every job
+    // The host's two 64-byte cache lines of the header each end their update with a copy of the sequence number (seq2 in word 31 first, then
+    // seq in word 0, both with release order after the fields): a poll that sees BOTH copies new has both halves at least that new.
+    const uint32_t h2 = ld_sys(&((const uint32_t*)slot)[laneId & 31u]);
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)h2, 0);
+    if (seq != last && (uint32_t)__builtin_amdgcn_readlane((int)h2, 31) == seq) {
+      auto word = [&](int i) { return (uint32_t)__builtin_amdgcn_readlane((int)h2, i); };
       LaunchParams P = S.base;
-      P.accel = slot->accel;
+      AccelDesc A;
+      uint32_t aw[sizeof(AccelDesc) / 4];
+#pragma unroll
+      for (int i = 0; i < (int)(sizeof(AccelDesc) / 4); i++) aw[i] = word(8 + i);
+      __builtin_memcpy(&A, aw, sizeof(AccelDesc));
+      P.accel = A;
       P.rays = slot->rays;
-      P.count = min(__builtin_amdgcn_readfirstlane(slot->count), (uint32_t)SERVICE_SLOT_RAYS);
-      P.occluded = __builtin_amdgcn_readfirstlane(slot->occluded);
+      P.count = min(word(1), (uint32_t)SERVICE_SLOT_RAYS);
+      P.occluded = word(2);
       P.stride = P.occluded ? 48u : 80u;
-      P.instID = __builtin_amdgcn_readfirstlane(slot->instID);
-      P.spillDepth = min(__builtin_amdgcn_readfirstlane(slot->spillDepth), S.base.spillDepth);
+      P.instID = word(3);
+      P.spillDepth = min(word(4), S.base.spillDepth);
       if (P.occluded) trace_body<Leaf, ROBUST, true, false, true, true>(P, ldsStack, octX[threadIdx.x >> 6]);
       else trace_body<Leaf, ROBUST, false, false, true, true>(P, ldsStack, octX[threadIdx.x >> 6]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the hit records (host memory) before the sequence number
