@@ -221,9 +221,6 @@ struct GridCellLeaf
 // their four child boxes as floats (96 B, plane-major: lx[4] ux[4] ly[4] uy[4] lz[4] uz[4]) instead of a 4-byte code of planes
 // relative to the parent box - nothing to decode and nothing inherited from the parent, so a descent carries only the node index.
 enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2, MODE_FULL = 3 };
-#ifndef TRACE_CBVH_PRELOAD
-#define TRACE_CBVH_PRELOAD 1 // quad form: node words of the first two levels requested with the header (CbvhCtx::pre)
-#endif
 #ifndef TRACE_CBVH_PREFETCH
 #define TRACE_CBVH_PREFETCH 0 // measured r2 (profiles/r02_prefetch_and_priority_ab.txt): 2-3 % slower alone and in flight - the later lines are not what a blob visit waits for
 #endif
@@ -278,10 +275,6 @@ struct CbvhCtx
   float near, zFactor;
   uint32_t special; // 0/1 in a vector register (see RayState::hit)
   const float* row; // quad form only: the ray's exchange row (org at words 0..2), so that the origin need not stay in registers
-  // quad form, coded modes (round 3, TRACE_CBVH_PRELOAD): the node words of the first TWO levels below the root - pre[0] = word of the root's child q,
-  // requested together with the header; pre[1 + p] = word of child q of the root's child p, requested when the root is entered - so that a walk meets
-  // the header, (hidden behind the root's test) one load of node words, and the cells, instead of one dependent load per level
-  uint32_t pre[5];
 #ifdef RTAMD_TRACE_RAY
   uint32_t dbgRay; // development aid: -DRTAMD_TRACE_RAY=<index> prints the cell tests of that ray (tools/fork_diff.py)
 #endif
@@ -621,7 +614,7 @@ __device__ __forceinline__ uint32_t quad_ballot(bool p, uint32_t lid) { return (
 // Row layout while a quad walks a blob (words of the ray's exchange row): 0..2 ray origin (kept for the flat-frame distance), 3 world
 // distance of the hit so far, 4 `near`, 5 zFactor, 6 `special`, 7 / 8 u / v of the hit so far, 9 hit flag.  The commit-only part of
 // the context and the hit itself live there instead of in seven registers; all four lanes write the same values.
-enum : int { QR_TFAR = 3, QR_NEAR = 4, QR_ZFACTOR = 5, QR_SPECIAL = 6, QR_U = 7, QR_V = 8, QR_HIT = 9, QR_TRAVFAR = 11 };
+enum : int { QR_TFAR = 3, QR_NEAR = 4, QR_ZFACTOR = 5, QR_SPECIAL = 6, QR_U = 7, QR_V = 8, QR_HIT = 9 };
 template <int MODE, int LEVELS>
 __device__ __forceinline__ void quad_commit(CbvhCtx& c, float u, float v, float t) // cbvh_commit for the leaf / box modes of the quad form
 {
@@ -661,17 +654,7 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
     const float* N = CbvhGeom<LEVELS>::fullNode(c.H, curr) + q;
     lx = N[0]; ux = N[4]; ly = N[8]; uy = N[12]; lz = N[16]; uz = N[20];
   } else {
-    if constexpr (REM > 1 && TRACE_CBVH_PRELOAD && REM == LEVELS) {
-      cw = c.pre[0];
-      // the words of the level below, requested while the root's children are decoded and tested (registers are short during the frustum test:
-      // with these four loads up there the metric kernel spilled one VGPR)
-      if constexpr (LEVELS >= 3) {
-        const uint32_t* N = CbvhGeom<LEVELS>::nodes(c.H);
-        c.pre[1] = N[5u + q]; c.pre[2] = N[9u + q]; c.pre[3] = N[13u + q]; c.pre[4] = N[17u + q];
-      }
-    }
-    else if constexpr (REM > 1 && TRACE_CBVH_PRELOAD && REM == LEVELS - 1) cw = curr == 1u ? c.pre[1] : (curr == 2u ? c.pre[2] : (curr == 3u ? c.pre[3] : c.pre[4]));
-    else if constexpr (REM > 1) cw = CbvhGeom<LEVELS>::nodes(c.H)[4u * curr + 1u + q];
+    if constexpr (REM > 1) cw = CbvhGeom<LEVELS>::nodes(c.H)[4u * curr + 1u + q];
     else if constexpr (MODE == MODE_LEAF) cw = ((const uint16_t*)CbvhGeom<LEVELS>::leaves(c.H))[4u * curr + 1u + q - CbvhGeom<LEVELS>::ELEMS];
     // getNode, compressed_node.h:488-510, the planes of child q only (x column = q & 1, y row = q >> 1)
     const float dimX = bhx - blx, dimY = bhy - bly, dimZ = bhz - blz;
@@ -693,7 +676,7 @@ __device__ __forceinline__ void quad_node(CbvhCtx& c, uint32_t lid, uint32_t cur
   const float nY = ((negy ? uy : ly) - c.oy) * c.rny, fY = ((negy ? ly : uy) - c.oy) * rfy;
   const float nZ = ((negz ? uz : lz) - c.oz) * c.rnz, fZ = ((negz ? lz : uz) - c.oz) * rfz;
   const float tN = fmaxf(fmaxf(nX, nY), fmaxf(nZ, 0.f));
-  const float tF = fminf(fminf(fX, fY), fminf(fZ, c.row[QR_TRAVFAR])); // travRay.tfar, fixed for the whole blob: kept in the ray's row, not in a register
+  const float tF = fminf(fminf(fX, fY), fminf(fZ, c.travFar));
   const bool h = tN <= tF;
   const uint32_t nhit = (uint32_t)__popc(quad_ballot(h, lid));
   if (nhit == 0u) return;
@@ -822,11 +805,7 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     c.H = H;
     c.r = &r;
     c.row = x;
-    const uint32_t rootWord = H->rootWord; // line 0 (accel.h): nothing outside it is needed before the frustum test
-    if constexpr (MODE != MODE_FULL && TRACE_CBVH_PRELOAD) { // requested now, needed only by a walk: the frustum test below does not wait for them
-      const uint32_t* N = CbvhGeom<LEVELS>::nodes(H);
-      c.pre[0] = LEVELS >= 2 ? N[1u + q] : 0u;
-    }
+    const uint32_t rootWord = H->rootWord; // line 0 (accel.h): nothing outside it is read before the frustum test
     // rotate the ray into the local frame (:458-459), on all four lanes
     const float* S = H->space;
     const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
@@ -893,8 +872,7 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
       c.zFactor = ldz / c.dz;
       c.tfar = (r.tfar - near) * c.zFactor;
     }
-    x[QR_TRAVFAR] = c.tfar; // every lane of the quad writes the same value
-    c.travFar = 0.f;
+    c.travFar = c.tfar;
     { // rdir_near of the local ray: one reciprocal per lane
       const float dq = q == 0u ? c.dx : (q == 1u ? c.dy : c.dz);
       const float rq = 1.0f / (fabsf(dq) < 1e-18f ? 1e-18f : dq);
