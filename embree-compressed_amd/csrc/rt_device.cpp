@@ -91,6 +91,7 @@ Device::Device(const char* cfg)
   if (const char* env = getenv("RTAMD_HOST_THREADS")) tuneHostThreads = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_PIPE_MIN")) tunePipeMinRays = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_PIPE_CHUNK")) tunePipeChunk = (uint32_t)std::max(64, atoi(env));
+  if (const char* env = getenv("RTAMD_WALK_BATCH")) tuneWalkBatch = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_OCT_MAX")) tuneOctMax = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_KERNEL")) tunePoolKernel = strcmp(env, "pool") == 0 ? 1u : (strcmp(env, "lane") == 0 ? 0u : 2u);
   if (const char* env = getenv("RTAMD_BLOCKS_PER_CU")) { tuneBlocksPerCU = (uint32_t)std::max(0, atoi(env)); tuneBlocksAuto = false; }

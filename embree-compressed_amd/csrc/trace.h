@@ -28,6 +28,7 @@ struct LaunchParams
   uint32_t refillBatch;    // idle lanes needed before a wave fetches new rays (tuning knob, env RTAMD_REFILL_BATCH)
   uint32_t octSteps;       // node steps an octet stays with its ray while the queues still have rays (env RTAMD_OCT_STEPS; unlimited in the drain)
   uint32_t octLeaf;        // waiting rays from which the child-parallel leaf step runs (0 = never; env RTAMD_OCT_LEAF)
+  uint32_t walkBatch;      // two-stage leaves: parked rays from which the walk stage runs (env RTAMD_WALK_BATCH)
   uint32_t octMax;         // lanes with node work up to which a wave runs the child-parallel node step (0 = never; env RTAMD_OCT_MAX)
   uint32_t* queues;        // TRACE_QUEUES work-queue heads, zeroed on the stream before the launch
   // Filter-function re-trace (row f3): ray i skips the triangles (geomID, primID) listed in

@@ -74,6 +74,10 @@ static constexpr int OCT_WORDS = 12; // TravRay (7) + travFar + cur + sp + owner
 // per lane in the subdivision kernels (the whole loop then runs 20 % slower), so one pass at a time it is
 static constexpr int OCT_PIPE = TRACE_OCT_PIPE;
 enum : int { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_XOR3 = 0x1B, DPP_HALF_MIRROR = 0x141 }; // quad_perm / row_half_mirror
+// leaves whose visit splits into a cheap test and a walk declare `static constexpr bool TWO_STAGE` (and frustum_pass); see the leaf step
+template <typename Leaf, typename = void> struct leaf_two_stage { static constexpr bool value = false; };
+template <typename Leaf> struct leaf_two_stage<Leaf, decltype((void)Leaf::TWO_STAGE)> { static constexpr bool value = Leaf::TWO_STAGE; };
+
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_u32(uint32_t v)
 {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
@@ -138,7 +142,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
   float travFar = 0.f;
   uint32_t sp = 0, cur = REF_EMPTY, rayIdx = 0;
   // lane state bits (vector register, see RayState::hit): ST_ACTIVE = the lane owns a ray, ST_POP = its next event is a pop
-  enum : uint32_t { ST_ACTIVE = 1u, ST_POP = 2u };
+  // ST_WALK (two-stage leaves): the ray passed the cheap first stage of its leaf and waits for the walk
+  enum : uint32_t { ST_ACTIVE = 1u, ST_POP = 2u, ST_WALK = 4u };
   uint32_t st = 0u;
   r.hit = 0u;
 
@@ -528,9 +533,63 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     // (lanes whose node step just ended at a leaf count as waiting: they need no extra iteration to get there)
     const bool atLeafNow = st == ST_ACTIVE && (cur & REF_LEAF);
     const bool atNodeNext = st == ST_ACTIVE && !(cur & REF_LEAF);
-    const uint64_t leafMask = __ballot(atLeafNow);
-    if (leafMask != 0ull) {
+    // Two-stage leaves (cBVH blobs, quad form): a visit is a cheap test (the frustum test: ~150 wave instructions for 16 rays, no
+    // divergence; it ends 28 % of the visits of the metric's rays) and a long, divergent walk.  Run together, a pass lasts as long
+    // as its longest walk, the lanes of the rays that left at the test idle, and a pass starts as soon as the wave runs out of node
+    // work - typically with 10 of 16 quads filled.  Run apart, the tests go through as the rays arrive and the rays that passed are
+    // parked (ST_WALK) until P.walkBatch of them wait - over several iterations - or the wave has nothing else to do; then full walk
+    // passes serve them.  Per ray the order of events is unchanged (a parked ray does nothing else), so the results are, byte for
+    // byte.  Measured round 3 (profiles/r03_two_stage_ab.txt): kernel alone 143 -> 137 us, four batches in flight +3 %; parking
+    // without the test stage gains nothing.
+    constexpr bool TWO_STAGE = !OCCLUDED && leaf_two_stage<Leaf>::value;
+    bool walkNow = false;
+    if constexpr (TWO_STAGE) {
+      const uint64_t newMask = __ballot(atLeafNow);
       const bool nodeWork = __ballot(atNodeNext) != 0ull;
+      const uint32_t nNew = (uint32_t)__popcll(newMask);
+      if constexpr (!Leaf::TWO_STAGE_TEST) { // development variant: no test stage, arrivals are parked at once
+        if (atLeafNow) { if (COUNT) wc.leaves++; st |= ST_WALK; }
+      } else
+      if (nNew != 0u && (nNew >= max(P.octLeaf, 1u) || !nodeWork)) {
+        if (COUNT) nLeafPhase++;
+        uint32_t lid = laneId;
+        asm volatile("" : "+v"(lid));
+        const uint32_t myRow = lane_rank(newMask);
+        const uint32_t nRows = min(nNew, (uint32_t)OCT_ROWS);
+        const bool inPhase = atLeafNow && myRow < nRows;
+        if (inPhase) {
+          if (COUNT) wc.leaves++;
+          float* x = octX[myRow];
+          x[0] = r.ox; x[1] = r.oy; x[2] = r.oz; x[3] = r.tnear;
+          x[4] = r.dx; x[5] = r.dy; x[6] = r.dz; x[7] = r.tfar;
+          x[8] = __uint_as_float(cur);
+          x[9] = __uint_as_float(0u); // set by the quad when the ray passes
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        constexpr uint32_t GROUP = (uint32_t)Leaf::GROUP;
+        for (uint32_t base = 0; base < nRows; base += 64u / GROUP) {
+          const uint32_t row = base + lid / GROUP;
+          Leaf::frustum_pass(P, octX[min(row, nRows - 1u)], row < nRows, lid);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (inPhase) st |= __float_as_uint(octX[myRow][9]) != 0u ? ST_WALK : ST_POP;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      // the walk: enough parked rays, or nothing else left to do in this iteration (no node work, no new arrival waiting for its test,
+      // nobody about to pop) - every iteration makes progress, parked rays cannot wait for ever
+      const uint64_t parked = __ballot(st == (ST_ACTIVE | ST_WALK));
+      if (parked != 0ull) {
+        const bool other = nodeWork || __ballot(st == (ST_ACTIVE | ST_POP) || (st == ST_ACTIVE && (cur & REF_LEAF))) != 0ull;
+        walkNow = (uint32_t)__popcll(parked) >= P.walkBatch || !other;
+      }
+    }
+    const bool atLeaf = TWO_STAGE ? (walkNow && st == (ST_ACTIVE | ST_WALK)) : atLeafNow; // the rays of this iteration's leaf step
+    const uint64_t leafMask = __ballot(atLeaf);
+    if (leafMask != 0ull) {
+      const bool nodeWork = !TWO_STAGE && __ballot(atNodeNext) != 0ull; // (two-stage leaves: decided above)
       const uint32_t nLeaf = (uint32_t)__popcll(leafMask);
       bool leafDone = false;
       if constexpr (Leaf::OCTET) {
@@ -547,9 +606,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           asm volatile("" : "+v"(lid)); // see the node step: keeps the lane constants of this block out of the loop's live set
           const uint32_t myRow = lane_rank(leafMask);
           const uint32_t nRows = min(nLeaf, (uint32_t)OCT_ROWS);
-          const bool inPhase = atLeafNow && myRow < nRows;
+          const bool inPhase = atLeaf && myRow < nRows;
           if (inPhase) {
-            if (COUNT) wc.leaves++;
+            if (COUNT && !TWO_STAGE) wc.leaves++;
             float* x = octX[myRow];
             x[0] = r.ox; x[1] = r.oy; x[2] = r.oz; x[3] = r.tnear;
             x[4] = r.dx; x[5] = r.dy; x[6] = r.dz; x[7] = r.tfar;
@@ -591,13 +650,13 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
               }
             }
             travFar = OCCLUDED ? travFar : r.tfar; // tray.tfar = ray.tfar (bvh_intersector1.cpp:117)
-            st |= ST_POP;
+            st = ST_ACTIVE | ST_POP;
           }
         }
       }
       if (!Leaf::OCTET_ONLY && !leafDone && (nLeaf >= P.leafBatch || !nodeWork)) {
         if (COUNT) nLeafPhase++;
-        if constexpr (!Leaf::OCTET_ONLY) if (atLeafNow) {
+        if constexpr (!Leaf::OCTET_ONLY) if (atLeaf) {
           if (COUNT) wc.leaves++;
           if (Leaf::template intersect<OCCLUDED, COUNT>(P, cur, r, wc, rayIdx)) {
             r.tfar = -RT_INF; // bvh_intersector1.cpp:198-201

@@ -221,6 +221,9 @@ struct GridCellLeaf
 // their four child boxes as floats (96 B, plane-major: lx[4] ux[4] ly[4] uy[4] lz[4] uz[4]) instead of a 4-byte code of planes
 // relative to the parent box - nothing to decode and nothing inherited from the parent, so a descent carries only the node index.
 enum { MODE_BOX = 0, MODE_LEAF = 1, MODE_GRID = 2, MODE_FULL = 3 };
+#ifndef TRACE_CBVH_TWO_STAGE
+#define TRACE_CBVH_TWO_STAGE 1 // quad form: frustum tests and walks of blob visits run as separate, separately batched stages (trace_loop.hip.h)
+#endif
 #ifndef TRACE_CBVH_PREFETCH
 #define TRACE_CBVH_PREFETCH 0 // measured r2 (profiles/r02_prefetch_and_priority_ab.txt): 2-3 % slower alone and in flight - the later lines are not what a blob visit waits for
 #endif
@@ -769,6 +772,52 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
   // bytes of a blob of this mode and level (cbvh_blob_bytes, cbvh_encode.cpp)
   static constexpr uint32_t BLOB_BYTES = cbvh_stride(LEVELS, MODE);
 
+  // Local ray and frustum test of the quad form: rotate the ray into the blob's frame (compressed.h:458-459, on all four lanes), then
+  // intersect_frustum (compressed_help.h:109-133): edge q on lane q (t1x: corners 1-3, t2x: 2-4, t1y: 1-2, t2y: 3-4; corner j at
+  // box[2j], box[2j+1]), every lane combines the four values in the reference's order.  false = the ray leaves the blob here.
+  static __device__ __forceinline__ bool quad_frustum(const CbvhHeader* H, const RayState& r, uint32_t q, float& lox, float& loy, float& loz, float& ldx,
+                                                      float& ldy, float& ldz, float& near, float& far)
+  {
+    const float* S = H->space;
+    lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
+    loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
+    loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
+    ldx = madd(r.dx, S[0], madd(r.dy, S[1], r.dz * S[2]));
+    ldy = madd(r.dx, S[3], madd(r.dy, S[4], r.dz * S[5]));
+    ldz = madd(r.dx, S[6], madd(r.dy, S[7], r.dz * S[8]));
+    const float* B = H->box;
+    const uint32_t a = 2u + ((0x4020u >> (4u * q)) & 15u), b = 2u + ((0x6264u >> (4u * q)) & 15u); // start / end corner of edge q
+    const float tq = intersect_line(B[a], B[a + 1u], B[b], B[b + 1u], lox, loy, ldx, ldy);
+    const float t1x = dpp_f32<DPP_Q0>(tq), t2x = dpp_f32<DPP_Q1>(tq), t1y = dpp_f32<DPP_Q2>(tq), t2y = dpp_f32<DPP_Q3>(tq);
+    const float rz = 1.0f / (fabsf(ldz) < 1e-18f ? 1e-18f : ldz); // rcp_safe
+    const float orz = loz * rz;
+    const float t1z = B[0] * rz - orz, t2z = B[1] * rz - orz;
+    const float near1 = fminf(fminf(t1x, t2x), fminf(t1y, t2y));
+    const float far1 = fmaxf(fmaxf(t1x, t2x), fmaxf(t1y, t2y));
+    near = fmaxf(fmaxf(fminf(t1z, t2z), near1), r.tnear);
+    far = fminf(fminf(fmaxf(t1z, t2z), far1), r.tfar);
+    return near <= far && near1 == near1 && far1 == far1;
+  }
+
+  // Two-stage blob visits (trace_loop.hip.h): the frustum test alone, for the ray in exchange row `x`; lane 0 of the quad sets word 9
+  // when the ray passes.  On the metric's rays 28 % of the visits end here; the walk (octet_pass) runs later, for the rays that
+  // passed, batched over several leaf phases - it repeats the test on the same ray and header, so the two decisions agree.
+  static constexpr bool TWO_STAGE = QUAD && TRACE_CBVH_TWO_STAGE != 0;
+  static constexpr bool TWO_STAGE_TEST = TRACE_CBVH_TWO_STAGE == 1; // 2 = development variant: arrivals are parked without the test stage
+  static __device__ __forceinline__ void frustum_pass(const LaunchParams& P, float* x, bool valid, uint32_t lid)
+  {
+    if (!valid) return; // uniform within the quad
+    const uint32_t q = lid & 3u;
+    RayState r;
+    r.ox = x[0]; r.oy = x[1]; r.oz = x[2]; r.tnear = x[3];
+    r.dx = x[4]; r.dy = x[5]; r.dz = x[6]; r.tfar = x[7];
+    const uint32_t idx = __float_as_uint(x[8]) & 0x7FFFFFFFu;
+    const CbvhHeader* H = (const CbvhHeader*)(P.accel.blobs + (size_t)idx * P.accel.blobStride);
+    float lox, loy, loz, ldx, ldy, ldz, near, far;
+    const bool pass = quad_frustum(H, r, q, lox, loy, loz, ldx, ldy, ldz, near, far);
+    if (q == 0u && pass) x[9] = __uint_as_float(1u);
+  }
+
   // Quad form of intersect() below for the ray in exchange row `x` (words 0..7 = org, tnear, dir, tfar; word 8 = leaf ref); lane
   // q of the quad `lid >> 2`.  On a hit lane 0 of the quad writes tfar, u, v, geomID, primID into words 0, 4..7 and sets word 9.
   template <bool OCCLUDED, bool COUNT>
@@ -806,31 +855,8 @@ template <int MODE, int LEVELS, bool QUAD = true> struct CbvhLeaf
     c.r = &r;
     c.row = x;
     const uint32_t rootWord = H->rootWord; // line 0 (accel.h): nothing outside it is read before the frustum test
-    // rotate the ray into the local frame (:458-459), on all four lanes
-    const float* S = H->space;
-    const float lox = madd(r.ox, S[0], madd(r.oy, S[1], r.oz * S[2]));
-    const float loy = madd(r.ox, S[3], madd(r.oy, S[4], r.oz * S[5]));
-    const float loz = madd(r.ox, S[6], madd(r.oy, S[7], r.oz * S[8]));
-    const float ldx = madd(r.dx, S[0], madd(r.dy, S[1], r.dz * S[2]));
-    const float ldy = madd(r.dx, S[3], madd(r.dy, S[4], r.dz * S[5]));
-    const float ldz = madd(r.dx, S[6], madd(r.dy, S[7], r.dz * S[8]));
-    // intersect_frustum (compressed_help.h:109-133): edge q on lane q (t1x: corners 1-3, t2x: 2-4, t1y: 1-2, t2y: 3-4; corner j at
-    // box[2j], box[2j+1]), then every lane combines the four values in the reference's order
-    float near = r.tnear, far = r.tfar;
-    {
-      const float* B = H->box;
-      const uint32_t a = 2u + ((0x4020u >> (4u * q)) & 15u), b = 2u + ((0x6264u >> (4u * q)) & 15u); // start / end corner of edge q
-      const float tq = intersect_line(B[a], B[a + 1u], B[b], B[b + 1u], lox, loy, ldx, ldy);
-      const float t1x = dpp_f32<DPP_Q0>(tq), t2x = dpp_f32<DPP_Q1>(tq), t1y = dpp_f32<DPP_Q2>(tq), t2y = dpp_f32<DPP_Q3>(tq);
-      const float rz = 1.0f / (fabsf(ldz) < 1e-18f ? 1e-18f : ldz); // rcp_safe
-      const float orz = loz * rz;
-      const float t1z = B[0] * rz - orz, t2z = B[1] * rz - orz;
-      const float near1 = fminf(fminf(t1x, t2x), fminf(t1y, t2y));
-      const float far1 = fmaxf(fmaxf(t1x, t2x), fmaxf(t1y, t2y));
-      near = fmaxf(fmaxf(fminf(t1z, t2z), near1), near);
-      far = fminf(fminf(fmaxf(t1z, t2z), far1), far);
-      if (!(near <= far && near1 == near1 && far1 == far1)) return;
-    }
+    float lox, loy, loz, ldx, ldy, ldz, near, far;
+    if (!quad_frustum(H, r, q, lox, loy, loz, ldx, ldy, ldz, near, far)) return;
     if (COUNT && q == 0u) wc.prims++; // counters of a cBVH accel: leaves = blob visits, prims = visits that pass the frustum test (walks), inner = quadtree nodes entered + cells tested
 #if TRACE_CBVH_PREFETCH
     asm volatile("" ::"v"(pf)); // (loads return in order: this costs no wait beyond the header's)
