@@ -168,8 +168,8 @@ struct Device : RefCounted
   uint32_t tuneCullMinRays = 65536; // batches below this size go straight to the traversal kernel (the extra launch costs ~5 us)
   uint32_t tuneAloneBlocksOct = 4; // env RTAMD_ALONE_BLOCKS: workgroups per CU of a batch alone on the chip, octet-only leaf kernels
   uint32_t tuneBusyBlocksOct = 2;  // env RTAMD_BUSY_BLOCKS: the same with two or more batches running on other streams
-  uint32_t tuneWalkBatch = 0xFFFFFFFFu; // env RTAMD_WALK_BATCH (trace_loop.hip.h, two-stage blob visits: rays parked after the frustum test before a walk pass runs);
-                                // auto: 24 for a batch alone on the chip, 12 with two or more other batches in flight (profiles/r03_two_stage_ab.txt)
+  uint32_t tuneWalkBatch = 16;  // env RTAMD_WALK_BATCH (trace_loop.hip.h, two-stage blob visits: rays parked after the frustum test before a walk pass runs;
+                                // 16 = one full pass of quads; measured 8..32, profiles/r03_two_stage_ab.txt)
   uint32_t tuneOctMax = 16;     // env RTAMD_OCT_MAX (trace_loop.hip.h, octet node step), clamped to the build's TRACE_OCT_MAX in the kernel
   // kernel tuning knobs (env RTAMD_CHUNK / RTAMD_LEAF_BATCH / RTAMD_BLOCKS_PER_CU).  Measured on MI355X, 1 M-ray batches:
   // alone on the chip every setting within chunk 128-256, leaf batch 24-40, 2-3 workgroups per CU is within +-4 %; with

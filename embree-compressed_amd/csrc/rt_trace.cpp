@@ -86,7 +86,7 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.leafBatch = dev->tuneLeafBatch;
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;
-  p.walkBatch = dev->tuneWalkBatch != 0xFFFFFFFFu ? dev->tuneWalkBatch : 24u; // (launch_on: 12 with other batches in flight)
+  p.walkBatch = dev->tuneWalkBatch;
   p.octSteps = dev->tuneOctSteps;
   // waiting rays from which the child-parallel leaf phase runs: triangle leaves 16, grid cells 24 (measured optima), cBVH blobs
   // (quad form, 16 rays per pass) 16
@@ -119,7 +119,6 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
     p.rayChunk = dev->tuneChunk; // in flight: coarse shares (see ray_chunk_for); the grid only shrinks, the overflow area was sized for the larger one
     p.gridBlocks = trace_grid_blocks(M, sh.numCUs, p.rayChunk);
   }
-  if (dev->tuneWalkBatch == 0xFFFFFFFFu && busyOther >= 2u) p.walkBatch = 12u; // fuller walk passes pay alone, shorter waits in flight
   p.queues = (uint32_t*)ctx.queues;
   // Root cull pre-pass (trace_cull.hip.h): large batches on the lane kernel whose root is an inner node.  Filter re-traces
   // (exclusion lists) are small and skip it.
@@ -734,7 +733,7 @@ static bool service_trace(Scene* s, char* rays, uint32_t M, size_t byteStride, b
       p.leafBatch = dev->tuneLeafBatch;
       p.refillBatch = dev->tuneRefillBatch;
       p.octMax = dev->tuneOctMax;
-      p.walkBatch = dev->tuneWalkBatch != 0xFFFFFFFFu ? dev->tuneWalkBatch : 24u;
+      p.walkBatch = dev->tuneWalkBatch;
       p.octSteps = dev->tuneOctSteps;
       p.octLeaf = dev->tuneOctLeaf != 0xFFFFFFFFu ? dev->tuneOctLeaf : (A.kind == ACCEL_GRIDSOA ? 24u : 16u);
       p.overflow = sh.overflowDev;

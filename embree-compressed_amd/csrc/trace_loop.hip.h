@@ -539,10 +539,10 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
     // work - typically with 10 of 16 quads filled.  Run apart, the tests go through as the rays arrive and the rays that passed are
     // parked (ST_WALK) until P.walkBatch of them wait - over several iterations - or the wave has nothing else to do; then full walk
     // passes serve them.  Per ray the order of events is unchanged (a parked ray does nothing else), so the results are, byte for
-    // byte.  Measured round 3 (profiles/r03_two_stage_ab.txt): kernel alone 143 -> 137 us, four batches in flight +3 %; parking
+    // byte.  Measured round 3 (profiles/r03_two_stage_ab.txt): kernel alone 144 -> 137 us, four batches in flight +5 %; parking
     // without the test stage gains nothing.
     constexpr bool TWO_STAGE = !OCCLUDED && leaf_two_stage<Leaf>::value;
-    bool walkNow = false;
+    bool walkNow = false, walkForced = false;
     if constexpr (TWO_STAGE) {
       const uint64_t newMask = __ballot(atLeafNow);
       const bool nodeWork = __ballot(atNodeNext) != 0ull;
@@ -583,7 +583,8 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       const uint64_t parked = __ballot(st == (ST_ACTIVE | ST_WALK));
       if (parked != 0ull) {
         const bool other = nodeWork || __ballot(st == (ST_ACTIVE | ST_POP) || (st == ST_ACTIVE && (cur & REF_LEAF))) != 0ull;
-        walkNow = (uint32_t)__popcll(parked) >= P.walkBatch || !other;
+        walkForced = !other;
+        walkNow = (uint32_t)__popcll(parked) >= P.walkBatch || walkForced;
       }
     }
     const bool atLeaf = TWO_STAGE ? (walkNow && st == (ST_ACTIVE | ST_WALK)) : atLeafNow; // the rays of this iteration's leaf step
@@ -605,7 +606,9 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
           uint32_t lid = laneId;
           asm volatile("" : "+v"(lid)); // see the node step: keeps the lane constants of this block out of the loop's live set
           const uint32_t myRow = lane_rank(leafMask);
-          const uint32_t nRows = min(nLeaf, (uint32_t)OCT_ROWS);
+          uint32_t nRows = min(nLeaf, (uint32_t)OCT_ROWS);
+          // (two-stage leaves: full passes only while the wave has other work - the remainder stays parked; in flight +2 %)
+          if (TWO_STAGE && !walkForced && nRows > 64u / (uint32_t)Leaf::GROUP) nRows = 64u / (uint32_t)Leaf::GROUP;
           const bool inPhase = atLeaf && myRow < nRows;
           if (inPhase) {
             if (COUNT && !TWO_STAGE) wc.leaves++;
