@@ -77,6 +77,7 @@ void Device::parse(const std::string& cfg)
 Device::Device(const char* cfg)
 {
   if (const char* env = getenv("RTAMD_GPU")) gpu = atoi(env);
+  if (const char* env = getenv("RTAMD_CHUNK_BUSY")) tuneChunkBusy = (uint32_t)std::max(1, atoi(env));
   if (const char* env = getenv("RTAMD_CHUNK")) { tuneChunk = (uint32_t)std::max(1, atoi(env)); tuneChunkFixed = true; }
   if (const char* env = getenv("RTAMD_SERVICE")) tuneService = (uint32_t)std::max(0, atoi(env));
   if (const char* env = getenv("RTAMD_LEAF_BATCH")) tuneLeafBatch = (uint32_t)std::max(1, atoi(env));

@@ -176,6 +176,7 @@ struct Device : RefCounted
   // four batches in flight 256 / 32 / 2 is +15-20 % over 128 / 24 / 3 (each kernel leaves the third wave slot of a SIMD
   // to the other batches, and takes its rays in fewer, larger grabs).
   uint32_t tuneChunk = 256, tuneLeafBatch = 32, tuneBlocksPerCU = 2;
+  uint32_t tuneChunkBusy = 512; // env RTAMD_CHUNK_BUSY: upper bound of the chunk of a large batch launched while two or more others run (rt_trace.cpp launch_on)
   bool tuneChunkFixed = false; // RTAMD_CHUNK given: every batch uses exactly that chunk (otherwise small batches are cut finer, rt_trace.cpp ray_chunk_for)
   // traversal skeleton: 0 lane-per-ray (trace_loop.hip.h), 1 ray pool (trace_pool.hip.h), 2 by batch size: the pool kernel's
   // steady state is 14 % faster, its drain slower - it wins from ~2.5 M rays per launch on (env RTAMD_KERNEL=lane|pool|auto)

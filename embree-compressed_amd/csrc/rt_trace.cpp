@@ -115,8 +115,13 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   // 13.3 -> 13.8 Grays/s, shadow rays 9.3 -> 9.8, camera rays 7.1 -> 7.7)
   const uint32_t busyBlocks = octOnly ? dev->tuneBusyBlocksOct : 1u;
   p.blocksPerCU = (dev->tuneBlocksAuto ? (busyOther >= 2u ? busyBlocks : (busyOther == 1u ? 2u : aloneBlocks)) : dev->tuneBlocksPerCU) * (256u / TRACE_BLOCK); // knob unit: 4 waves
-  if (busyOther >= 1u && M >= 100000u && !dev->tuneChunkFixed && p.rayChunk < dev->tuneChunk && !p.poolKernel) {
-    p.rayChunk = dev->tuneChunk; // in flight: coarse shares (see ray_chunk_for); the grid only shrinks, the overflow area was sized for the larger one
+  // With two or more other batches running, fewer and fuller wavefronts still (up to tuneChunkBusy = 512 rays per grab) as long as the batch
+  // keeps half of the chip's wavefront slots busy: 1 M rays 12.8 -> 13.05 Grays/s, eager 14.2 -> 14.7, triangles 18.3 -> 18.9; a flat 512
+  // loses 16-19 % at 131 k - 250 k rays (profiles/r03_chunk_busy_ab.txt)
+  uint32_t busyChunk = dev->tuneChunk;
+  if (busyOther >= 2u) busyChunk = std::min(std::max(dev->tuneChunk, (M / ((uint32_t)sh.numCUs * 8u)) & ~63u), std::max(dev->tuneChunk, dev->tuneChunkBusy));
+  if (busyOther >= 1u && M >= 100000u && !dev->tuneChunkFixed && p.rayChunk < busyChunk && !p.poolKernel) {
+    p.rayChunk = busyChunk; // in flight: coarse shares (see ray_chunk_for); the grid only shrinks, the overflow area was sized for the larger one
     p.gridBlocks = trace_grid_blocks(M, sh.numCUs, p.rayChunk);
   }
   p.queues = (uint32_t*)ctx.queues;
