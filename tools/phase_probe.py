@@ -6,7 +6,9 @@ rtc = importlib.import_module('embree-compressed_amd').rtc
 raygen = importlib.import_module('embree-compressed_amd.raygen')
 d = np.load('/root/repo/assets/bomberman.mesh.npz'); v, fs, fi = d['verts'], d['face_sizes'], d['face_index']
 lo, hi = v.min(0), v.max(0)
+only = sys.argv[1:]
 for name, cfg, sub in (('cbvh.leaf', 'subdiv_accel=bvh4.compressed.leaf', True), ('eager', 'subdiv_accel=default', True), ('tri', 'tri_accel=bvh8.triangle4v', False)):
+    if only and name not in only: continue
     dev = rtc.Device('gpu=0,' + cfg); sc = rtc.Scene(dev)
     if sub: sc.add_subdiv(v, fs, fi); sc.set_levels(6, 3)
     else: sc.add_triangles(v, rtc.fan_triangulate(fs, fi))
