@@ -431,7 +431,7 @@ def main():
                 "bytes_per_ray_addressed": R["bytes_per_ray_addressed"],
                 "frac_addressed": R["bytes_per_ray_addressed"] * R["m"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "frac_note": "achieved / frac price ALGORITHMIC bytes (SURVEY.md 8d: every node / leaf record a ray visits, L1 / L2 hits "
-                             "included; a blob visit = the whole padded record, an upper bound - most visits end at the frustum test) against the HBM "
+                             "included; a blob visit = the whole padded record, an upper bound - 28 % of the visits end at the frustum test, a walk reads a fraction of the record) against the HBM "
                              "peak; bytes_per_ray_addressed / frac_addressed price a blob visit at the fields it reads (bench.py addressed_bytes_per_ray); "
                              "`traffic` is what the PMC counters saw reach HBM per launch",
                 "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None}
