@@ -64,7 +64,11 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.occluded = occluded ? 1u : 0u;
   p.rayChunk = ray_chunk_for(dev, M, sh.numCUs);
   p.gridBlocks = trace_grid_blocks(M, sh.numCUs, p.rayChunk);
-  p.poolKernel = dev->tunePoolKernel == 2u ? (M >= dev->tunePoolMinRays ? 1u : 0u) : dev->tunePoolKernel;
+  // Ray-pool skeleton for very large batches - where it still pays.  Since the two-stage blob visits and the batched leaf passes of round 3 the lane
+  // kernel is the faster one at EVERY size for grid cells and the cBVH box / leaf / full modes (4 M rays, one stream: cbvh.leaf 12.0 vs 10.2 Grays/s,
+  // eager 6 M 14.5 vs 10.7); the pool keeps triangles (6 M: 16.8 vs 14.8) and the cBVH grid mode (11.0 vs 8.3).  profiles/r03_lane_pool_ab.txt
+  const bool poolPays = A.kind == ACCEL_TRI_PLUECKER || A.kind == ACCEL_TRI_MOELLER || A.kind == ACCEL_CBVH_GRID;
+  p.poolKernel = dev->tunePoolKernel == 2u ? (poolPays && M >= dev->tunePoolMinRays ? 1u : 0u) : dev->tunePoolKernel;
   // worst-case stack: 7 siblings per level plus the entry being expanded.  The overflow area is sized for it, so a push
   // can only be dropped if the tree is deeper than the builder reported; the kernels then raise `overflow` (below).
   const uint32_t worst = 7u * (A.maxDepth + 1u) + 2u;
