@@ -81,8 +81,8 @@ static_assert(sizeof(GridCell) == 160, "GridCell must be 160 bytes");
 // stub.  Round 3 layout, ordered by WHEN a visit needs a field, in 128-byte lines (the blob stride is a multiple of 128 and the
 // blob array is 128-byte aligned, so a line of a blob is a line of L2 / HBM):
 //   line 0  (CbvhHeader, bytes 0..127)   everything up to and including the frustum test and the projected ray: space, box, proj, a
-//           copy of the root node's word, rcp_edges, extent.  Most visits of incoherent rays end at the frustum test
-//           (compressed_help.h:109-133): they touch this ONE line (round 2: the same fields lay in two or three lines of a 448-byte
+//           copy of the root node's word, rcp_edges, extent.  The visits that end at the frustum test (compressed_help.h:109-133; 28 % of the
+//           metric's, nearly all of a grazing ray's) and the test stage of the two-stage visits touch this ONE line (round 2: the same fields lay in two or three lines of a 448-byte
 //           record that started on a line boundary only every other blob).
 //   line 1  (CbvhMid, bytes 128..159, then the nodes from byte 160)   ids + uv window (commit only) and the 4-byte node words
 //           (compressed_node.h:261-295); C = 3: 32 + 84 bytes, one line.

@@ -12,6 +12,10 @@
 #pragma once
 #include "trace_loop.hip.h"
 
+#ifndef TRACE_SERVICE_SLEEP
+#define TRACE_SERVICE_SLEEP 8 // s_sleep units (64 cycles) between two idle polls
+#endif
+
 namespace rtamd {
 namespace dev {
 
@@ -63,14 +67,17 @@ __global__ __launch_bounds__(TRACE_BLOCK, 2) void service_kernel(ServiceParams S
       idle = 0;
       quiet = 0;
     } else {
-      if (__builtin_amdgcn_readfirstlane(ld_sys(S.stop)) != 0u) break;
-      if ((++idle & 255u) == 0u) {
+      // (the stop word lives in host memory too: looked at every 16th idle poll, so that a poll is ONE PCIe round trip and a new job is seen sooner)
+      if ((++idle & 15u) == 0u && __builtin_amdgcn_readfirstlane(ld_sys(S.stop)) != 0u) break;
+      if ((idle & 255u) == 0u) {
         const uint32_t a = __builtin_amdgcn_readfirstlane(__hip_atomic_load(S.activity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         quiet = a == seen ? quiet + 256u : 0u;
         seen = a;
         if (quiet >= S.idlePolls) break; // nobody has served anything for idlePolls polls: the service ends, the host restarts it on demand
       }
-      __builtin_amdgcn_s_sleep(8);
+#if TRACE_SERVICE_SLEEP
+      __builtin_amdgcn_s_sleep(TRACE_SERVICE_SLEEP);
+#endif
     }
   }
 }

@@ -129,8 +129,14 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
     dev0.synchronize()
     hits = int((ref.view(torch.int32)[:, 18] != -1).sum().item())
     # (octet node threshold, octet / quad leaf threshold, root cull pre-pass, cBVH blob walk: one ray per lane / four lanes per ray)
-    for octmax, octleaf, cull, form in (("0", "0", "0", "lane"), ("8", "1", "1", "quad"), ("16", "8", "0", "quad"), ("32", "32", "1", "lane"), ("16", None, None, None)):
+    # + rays parked after the frustum test before a walk pass runs (two-stage blob visits of the quad form; None = the library's default, 16)
+    for octmax, octleaf, cull, form, walk in (("0", "0", "0", "lane", None), ("8", "1", "1", "quad", "1"), ("16", "8", "0", "quad", "40"),
+                                              ("32", "32", "1", "lane", None), ("16", None, None, None, None)):
         monkeypatch.setenv("RTAMD_OCT_MAX", octmax)
+        if walk is None:
+            monkeypatch.delenv("RTAMD_WALK_BATCH", raising=False)
+        else:
+            monkeypatch.setenv("RTAMD_WALK_BATCH", walk)
         if form is None:
             monkeypatch.delenv("RTAMD_CBVH_FORM")  # the library's own default: by the context's coherent flag (here: quad form)
         else:
@@ -144,7 +150,7 @@ def test_node_step_variants_and_counted_twin(rtc, bomberman, kind, monkeypatch):
         else:
             monkeypatch.setenv("RTAMD_OCT_LEAF", octleaf)
         dev, sc = scene()
-        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}, cull {cull}, cBVH form {form}"
+        what = f"{kind}: octet thresholds node {octmax} leaf {octleaf}, cull {cull}, cBVH form {form}, walk batch {walk}"
         for rep in range(2):
             got = rays.clone()
             sc.intersect1M(got)
