@@ -91,6 +91,7 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   p.refillBatch = dev->tuneRefillBatch;
   p.octMax = dev->tuneOctMax;
   p.walkBatch = dev->tuneWalkBatch;
+  p.inlineRay = 0u;
   p.octSteps = dev->tuneOctSteps;
   // waiting rays from which the child-parallel leaf phase runs: triangle leaves 16, grid cells 24 (measured optima), cBVH blobs
   // (quad form, 16 rays per pass) 16
@@ -794,6 +795,10 @@ static bool service_trace(Scene* s, char* rays, uint32_t M, size_t byteStride, b
   ServiceSlot& slot = sv->slotsHost[mySlot];
   const uint32_t rec = occluded ? (uint32_t)sizeof(RTCRay) : (uint32_t)sizeof(RTCRayHit);
   for (uint32_t i = 0; i < M; i++) memcpy(slot.rays + (size_t)i * rec, rays + (size_t)i * byteStride, rec);
+  if (M == 1u) { // the ray itself rides in the polled header line (trace_service.hip.h)
+    memcpy(slot.ray0, rays, 28);
+    memcpy(slot.ray0 + 7, rays + 32, 4);
+  }
   slot.count = M;
   slot.occluded = occluded ? 1u : 0u;
   slot.instID = instID;

@@ -28,6 +28,7 @@ struct LaunchParams
   uint32_t refillBatch;    // idle lanes needed before a wave fetches new rays (tuning knob, env RTAMD_REFILL_BATCH)
   uint32_t octSteps;       // node steps an octet stays with its ray while the queues still have rays (env RTAMD_OCT_STEPS; unlimited in the drain)
   uint32_t octLeaf;        // waiting rays from which the child-parallel leaf step runs (0 = never; env RTAMD_OCT_LEAF)
+  uint32_t inlineRay;      // service kernel (DIRECT), a job of one ray: its org, tnear, dir, tfar lie in words 0..7 of the wave's exchange row 0, not only in P.rays
   uint32_t walkBatch;      // two-stage leaves: parked rays from which the walk stage runs (env RTAMD_WALK_BATCH)
   uint32_t octMax;         // lanes with node work up to which a wave runs the child-parallel node step (0 = never; env RTAMD_OCT_MAX)
   uint32_t* queues;        // TRACE_QUEUES work-queue heads, zeroed on the stream before the launch
@@ -64,13 +65,14 @@ struct alignas(128) ServiceSlot // host-mapped pinned memory, one per wavefront 
   uint32_t spillDepth; // HBM stack overflow entries this scene's depth needs (<= what the service allocated)
   uint32_t pad0[3];
   AccelDesc accel;     // the committed scene's device arrays (replica of the service's GPU)
-  uint32_t pad1[32 - 8 - sizeof(AccelDesc) / 4 - 1];
+  float ray0[8];       // a job of ONE ray: org, tnear, dir, tfar of the record (words 0..6 and 8) again, so that the poll that sees the job has the ray as well
+  uint32_t pad1[32 - 8 - sizeof(AccelDesc) / 4 - 8 - 1];
   uint32_t seq2;       // copy of seq in the header's second 64-byte half, written BEFORE seq (trace_service.hip.h)
   uint32_t done;       // device -> host: sequence number of the last finished job (own 128-byte line)
   uint32_t pad2[31];
   char rays[SERVICE_SLOT_RAYS * 80];
 };
-static_assert(sizeof(ServiceSlot) == 256 + SERVICE_SLOT_RAYS * 80 && offsetof(ServiceSlot, done) == 128 && offsetof(ServiceSlot, seq2) == 124 && offsetof(ServiceSlot, rays) == 256, "ServiceSlot layout");
+static_assert(sizeof(ServiceSlot) == 256 + SERVICE_SLOT_RAYS * 80 && offsetof(ServiceSlot, done) == 128 && offsetof(ServiceSlot, seq2) == 124 && offsetof(ServiceSlot, ray0) == 80 && offsetof(ServiceSlot, rays) == 256, "ServiceSlot layout");
 struct ServiceParams
 {
   LaunchParams base;   // tuning knobs, overflow area, overflow flag; rays / count / accel come from the slot per job

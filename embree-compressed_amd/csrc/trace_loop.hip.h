@@ -239,7 +239,12 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
         if (!(st & ST_ACTIVE) && mine < poolEnd) {
           rayIdx = survivors ? survivors[mine] : mine;
           const char* rp = (const char*)P.rays + (size_t)rayIdx * P.stride;
-          load_ray<VEC>(rp, r);
+          if (DIRECT && P.inlineRay) { // (service kernel: the ray came with the polled slot header - no second read of host memory)
+            const float* x = octX[0];
+            r.ox = x[0]; r.oy = x[1]; r.oz = x[2]; r.tnear = x[3];
+            r.dx = x[4]; r.dy = x[5]; r.dz = x[6]; r.tfar = x[7];
+          } else
+            load_ray<VEC>(rp, r);
           r.hit = 0u;
           // stream front-end: rays with tnear > tfar are skipped (bvh_intersector_stream_filters.cpp:156);
           // occluded: already-occluded rays return early (bvh_intersector1.cpp:132-134)

@@ -56,6 +56,13 @@ __global__ __launch_bounds__(TRACE_BLOCK, 2) void service_kernel(ServiceParams S
       P.stride = P.occluded ? 48u : 80u;
       P.instID = word(3);
       P.spillDepth = min(word(4), S.base.spillDepth);
+      // a job of one ray carries the ray in the header (ServiceSlot::ray0 = words 20..27): into the wave's exchange row 0 for trace_body's fetch
+      P.inlineRay = P.count == 1u ? 1u : 0u;
+      if (P.inlineRay) {
+        if (laneId >= 20u && laneId < 28u) octX[threadIdx.x >> 6][0][laneId - 20u] = __uint_as_float(h2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
       if (P.occluded) trace_body<Leaf, ROBUST, true, false, true, true>(P, ldsStack, octX[threadIdx.x >> 6]);
       else trace_body<Leaf, ROBUST, false, false, true, true>(P, ldsStack, octX[threadIdx.x >> 6]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // the hit records (host memory) before the sequence number
