@@ -83,9 +83,11 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   }
   p.counters = dCounters;
   p.cbvhLevels = s->compressionLevel;
-  // coherent batches (RTC_INTERSECT_CONTEXT_FLAG_COHERENT, e.g. the primary rays of viewer_stream_device.cpp:305) keep most lanes at
-  // blobs at once: one ray per lane; everything else: quad form.  RTAMD_CBVH_FORM=quad|lane overrides.
-  p.cbvhLaneForm = dev->tuneCbvhForm == 2u ? (coherent ? 1u : 0u) : dev->tuneCbvhForm;
+  // cBVH blob walk: quad form (four lanes per ray, two-stage visits) or one ray per lane.  Coherent batches (RTC_INTERSECT_CONTEXT_FLAG_COHERENT,
+  // e.g. the primary rays of viewer_stream_device.cpp:305) keep most lanes at blobs at once; since the two-stage visits the quad form is the faster
+  // one for them too when the batch has the chip (1920x1080 camera rays alone: 0.630 vs 0.768 ms), the lane form still wins with several batches
+  // in flight (6.8 vs 6.2 Grays/s) - decided below, once the launch context says how many others are running.  RTAMD_CBVH_FORM=quad|lane overrides.
+  p.cbvhLaneForm = dev->tuneCbvhForm == 2u ? 0u : dev->tuneCbvhForm;
   p.numCUs = (uint32_t)sh.numCUs;
   p.leafBatch = dev->tuneLeafBatch;
   p.refillBatch = dev->tuneRefillBatch;
@@ -109,6 +111,7 @@ static void launch_on(Scene* s, const Accel& A, size_t si, void* dRays, uint32_t
   unsigned busyOther = 0;
   Device::LaunchCtx& ctx = sh.acquireLaunchCtx(spillBytes, &busyOther, stream);
   p.spill = ctx.spill;
+  if (dev->tuneCbvhForm == 2u && coherent && busyOther >= 2u) p.cbvhLaneForm = 1u;
   // A batch alone on the chip is fastest with two workgroups per CU; when two or more batches are running on other
   // streams a leaner grid is better: every wave pays its deepest ray's iterations, so fewer waves per batch waste fewer
   // instructions (measured: 11.2 -> 12.0 Grays/s with four batches in flight; alone 0.174 -> 0.237 ms, hence adaptive).
