@@ -508,7 +508,7 @@ def main():
     # than the 4 MiB L2s and the 256 MiB Infinity Cache, so that the blobs really come from HBM
     if default_line and args.scaled_levels != "none":
         lv2 = tuple(int(x) for x in args.scaled_levels.split(","))
-        Ks = min(K, 10)
+        Ks = min(K, 20)  # (regions of 10 steps read the in-flight rate ~15 % low)
         R3 = measure(args.workload, Ks, 2, lv=lv2, repeats=5)
         _, _, _, tag, desc = WORKLOADS[args.workload]
         sfx = f"_L{lv2[0]}"
