@@ -41,9 +41,6 @@ namespace dev {
 #ifndef TRACE_COUNT_MIN_WAVES
 #define TRACE_COUNT_MIN_WAVES(Leaf) 2
 #endif
-#ifndef TRACE_SOLO_VISITS
-#define TRACE_SOLO_VISITS 16 // two-stage leaves: arrivals up to which a wave with nothing else to do skips the test stage (trace_body, leaf step)
-#endif
 #ifndef TRACE_PHASE_STAMPS
 #define TRACE_PHASE_STAMPS 0
 #endif
@@ -555,11 +552,7 @@ __device__ __forceinline__ void trace_body(const LaunchParams& P, uint2 (*ldsSta
       const uint64_t newMask = __ballot(atLeafNow);
       const bool nodeWork = __ballot(atNodeNext) != 0ull;
       const uint32_t nNew = (uint32_t)__popcll(newMask);
-      // Nothing else to do in this iteration (no node work, nobody about to pop): the walk pass below runs now whatever the test says, so the
-      // arrivals join it directly - the pass tests the frustum itself - instead of paying a test pass first.  This is the state of a draining wave
-      // with a deep ray or two: one stage execution less per blob visit on the kernel's critical path.
-      const bool solo = TRACE_SOLO_VISITS != 0 && !nodeWork && nNew != 0u && nNew <= (uint32_t)TRACE_SOLO_VISITS && __ballot(st == (ST_ACTIVE | ST_POP)) == 0ull;
-      if (!Leaf::TWO_STAGE_TEST || solo) { // (TWO_STAGE_TEST = false: development variant, arrivals are parked at once)
+      if constexpr (!Leaf::TWO_STAGE_TEST) { // development variant: no test stage, arrivals are parked at once
         if (atLeafNow) { if (COUNT) wc.leaves++; st |= ST_WALK; }
       } else
       if (nNew != 0u && (nNew >= max(P.octLeaf, 1u) || !nodeWork)) {
