@@ -7,11 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("kind", ["tri", "cbvh.leaf"])
+@pytest.mark.parametrize("kind", ["tri", "cbvh.leaf", "cbvh.leaf.coherent"])
 def test_batches_on_several_streams_match_serial(rtc, po, bomberman, kind):
+    """(cbvh.leaf.coherent: the batches carry RTC_INTERSECT_CONTEXT_FLAG_COHERENT, for which the library picks the blob walk form - four lanes
+    per ray or one ray per lane - by the number of batches it finds running, so the pipelined batches mix both forms: same bytes.)"""
     import torch
 
     verts, fs, fi = bomberman
+    ctx = rtc.make_context(coherent=True) if kind.endswith(".coherent") else None
     if kind == "tri":
         dev = rtc.Device("tri_accel=bvh8.triangle4v")
         sc = rtc.Scene(dev)
@@ -27,14 +30,14 @@ def test_batches_on_several_streams_match_serial(rtc, po, bomberman, kind):
     src = [po.make_random_rays(n, lo, hi, seed=40 + b).view(np.uint8).reshape(n, 80) for b in range(nb)]
     serial = [torch.from_numpy(s.copy()).cuda() for s in src]
     for b in serial:
-        sc.intersect1M(b)
+        sc.intersect1M(b, ctx=ctx)
     dev.synchronize()
     streams = [torch.cuda.Stream() for _ in range(3)]
     piped = [torch.from_numpy(s.copy()).cuda() for s in src]
     torch.cuda.synchronize()
     for i, b in enumerate(piped):
         dev.set_stream(streams[i % 3].cuda_stream)
-        sc.intersect1M(b, check=False)
+        sc.intersect1M(b, ctx=ctx, check=False)
     torch.cuda.synchronize()
     dev.check("pipelined batches")
     nh = 0
