@@ -26,8 +26,13 @@ uint32_t trace_grid_blocks(uint32_t count, int numCUs, uint32_t rayChunk)
 static uint32_t ray_chunk_for(const Device* dev, uint32_t M, int numCUs)
 {
   if (dev->tuneChunkFixed) return dev->tuneChunk;
+  // the share that gives every resident wavefront exactly ONE grab: a queue owns ceil(M / TRACE_QUEUES) rays and serves waves / TRACE_QUEUES wavefronts.
+  // (1 M rays on 4096 wavefronts: 245, not 256 - 64 grabs per queue instead of 61 full ones and a rest of 9 rays; a wave that needs a second grab late
+  // doubles its life: 240 rays per grab cost +5 %, 245 gain 1.2 % over 256, profiles/r03_chunk_busy_ab.txt)
   const uint32_t waves = (uint32_t)numCUs * 16u;
-  const uint32_t share = ((M + waves - 1u) / waves + 15u) & ~15u;
+  const uint32_t perQ = (M + (uint32_t)TRACE_QUEUES - 1u) / (uint32_t)TRACE_QUEUES;
+  const uint32_t grabs = std::max(1u, waves / (uint32_t)TRACE_QUEUES);
+  const uint32_t share = (perQ + grabs - 1u) / grabs;
   return std::min(dev->tuneChunk, std::max(32u, share));
 }
 
